@@ -1,0 +1,27 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def r3d():
+    """The product package (its directory name starts with a digit, so it is imported by string)."""
+    return importlib.import_module("3d_reconstruction_project_amd")
+
+
+@pytest.fixture(scope="session")
+def synth():
+    return importlib.import_module("3d_reconstruction_project_amd.synth")
+
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")

@@ -1,0 +1,95 @@
+"""CPU tests of the SGBM oracle: known-answer tests + cross-check against an independent numpy restatement.
+(No reference golden vectors exist for this path -- SURVEY.md section 8c: parity unpinned vs real OpenCV.)"""
+import numpy as np
+import pytest
+
+from oracle import sgbm_oracle as so
+from tests import sgbm_numpy_ref as ref
+
+C2_KW = dict(minDisparity=0, blockSize=5, P1=8 * 3 * 25, P2=32 * 3 * 25, disp12MaxDiff=1, uniquenessRatio=15,
+             speckleWindowSize=0, speckleRange=2, preFilterCap=63)          # Calib_depth/depth2.py:139-158
+D4_KW = dict(minDisparity=0, blockSize=5, P1=8 * 3 * 25, P2=32 * 3 * 25, disp12MaxDiff=1, uniquenessRatio=10,
+             speckleWindowSize=50, speckleRange=32, preFilterCap=63)        # Calib_depth/depth4.py:156-168
+
+
+def test_constant_shift_known_answer(synth):
+    D, d0 = 32, 11
+    L, R = synth.constant_shift_pair(256, 80, d0, seed=3)
+    disp = so.compute(L, R, so.make_params(numDisparities=D, **C2_KW))
+    assert disp.dtype == np.int16 and disp.shape == L.shape
+    assert (disp[:, :D] == -16).all()                       # columns x < minX1 are invalid = (minD-1)*16
+    inner = disp[6:-6, D + 6:-6]
+    assert (np.abs(inner.astype(int) - 16 * d0) <= 1).all()
+    assert (inner == 16 * d0).mean() > 0.95
+
+
+@pytest.mark.parametrize("kw,D,shape,seed", [
+    (C2_KW, 16, (24, 48), 0), (C2_KW, 32, (21, 70), 1), (D4_KW, 16, (30, 52), 2),
+    (dict(C2_KW, blockSize=3, P1=72, P2=288), 16, (17, 40), 3),
+    (dict(C2_KW, blockSize=7, P1=8 * 3 * 49, P2=32 * 3 * 49, uniquenessRatio=0), 16, (26, 44), 4),
+])
+def test_c_oracle_equals_numpy_restatement(kw, D, shape, seed, synth):
+    H, W = shape
+    L, R, _ = synth.stereo_pair(W, H, D, seed=seed)
+    got, got_raw = so.compute(L, R, so.make_params(numDisparities=D, **kw), return_raw=True)
+    want, want_raw = ref.compute(L, R, numDisparities=D, return_raw=True, **kw)
+    np.testing.assert_array_equal(got_raw, want_raw)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_random_noise_images_match(synth):
+    rng = np.random.default_rng(9)
+    L = rng.integers(0, 256, (20, 44), dtype=np.uint8)
+    R = rng.integers(0, 256, (20, 44), dtype=np.uint8)
+    got = so.compute(L, R, so.make_params(numDisparities=16, **C2_KW))
+    want = ref.compute(L, R, numDisparities=16, **C2_KW)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_negative_min_disparity_right_matcher_geometry(synth):
+    """createRightMatcher semantics: minD = -(D-1), compute(right, left)."""
+    D = 16
+    L, R, _ = synth.stereo_pair(60, 22, D, seed=7)
+    kw = dict(C2_KW, minDisparity=-(0 + D) + 1, uniquenessRatio=0, disp12MaxDiff=1000000)
+    got = so.compute(R, L, so.make_params(numDisparities=D, **kw))
+    want = ref.compute(R, L, numDisparities=D, **kw)
+    np.testing.assert_array_equal(got, want)
+    assert (got[:, -(D - 1):] == (kw["minDisparity"] - 1) * 16).all()
+
+
+def test_threads_do_not_change_result(synth):
+    L, R, _ = synth.stereo_pair(160, 120, 32, seed=11)
+    p = so.make_params(numDisparities=32, **C2_KW)
+    np.testing.assert_array_equal(so.compute(L, R, p, nthreads=1), so.compute(L, R, p, nthreads=4))
+
+
+def test_two_plane_step_edge(synth):
+    D = 32
+    rng = np.random.default_rng(5)
+    tex = rng.integers(0, 256, (64, 300)).astype(np.uint8)
+    from scipy.ndimage import uniform_filter
+    tex = np.clip(uniform_filter(tex.astype(float), 2) * 1.0, 0, 255).astype(np.uint8)
+    W = 200
+    L = tex[:, :W].copy()
+    R = np.empty_like(L)
+    R[:32] = tex[:32, 5:5 + W]          # top half: disparity 5
+    R[32:] = tex[32:, 12:12 + W]        # bottom half: disparity 12
+    disp = so.compute(L, R, so.make_params(numDisparities=D, **C2_KW))
+    assert (disp[4:26, D + 8:-16] == 5 * 16).mean() > 0.97
+    assert (disp[38:60, D + 8:-16] == 12 * 16).mean() > 0.97
+
+
+def test_filter_speckles_matches_union_find():
+    rng = np.random.default_rng(3)
+    img = (rng.integers(0, 6, (40, 50)) * 40).astype(np.int16)
+    img[rng.random(img.shape) < 0.2] = -16
+    got = so.filter_speckles(img, -16, 6, 32)
+    want = ref.speckles(img, -16, 6, 32)
+    np.testing.assert_array_equal(got, want)
+    assert (got == -16).sum() > (img == -16).sum()
+
+
+def test_bad_params_rejected():
+    L = np.zeros((8, 40), np.uint8)
+    with pytest.raises(RuntimeError):
+        so.compute(L, L, so.make_params(numDisparities=24, blockSize=5))
