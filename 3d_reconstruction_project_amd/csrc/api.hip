@@ -1,0 +1,209 @@
+// api.hip -- context, memory/timing helpers and the extern "C" entry points declared in include/r3d.h.
+#include <stdarg.h>
+#include <string.h>
+
+#include "r3d_internal.h"
+
+static std::string g_init_err;
+
+int r3d_fail(r3d_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_init_err = buf;
+    return code;
+}
+
+int r3d_reserve(r3d_ctx *ctx, r3d_buf &b, size_t bytes) {
+    if (bytes <= b.cap) return R3D_OK;
+    if (b.p) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 4096;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return r3d_fail(ctx, R3D_E_OOM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    b.cap = want;
+    return R3D_OK;
+}
+
+extern "C" {
+
+int r3d_init(int device, r3d_ctx **out) {
+    if (!out) return r3d_fail(nullptr, R3D_E_BADARG, "r3d_init: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return r3d_fail(nullptr, R3D_E_NODEVICE, "r3d_init: no HIP device (%s)", e != hipSuccess ? hipGetErrorString(e) : "count=0");
+    if (device < 0 || device >= n) return r3d_fail(nullptr, R3D_E_BADARG, "r3d_init: device %d out of range [0,%d)", device, n);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess)
+        return r3d_fail(nullptr, R3D_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return r3d_fail(nullptr, R3D_E_NODEVICE, "r3d_init: device %d is %s; this library contains gfx950 code only", device, prop.gcnArchName);
+    r3d_ctx *ctx = new (std::nothrow) r3d_ctx();
+    if (!ctx) return r3d_fail(nullptr, R3D_E_OOM, "r3d_init: out of host memory");
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+        int rc = r3d_fail(nullptr, R3D_E_HIP, "r3d_init: %s", hipGetErrorString(e));
+        delete ctx;
+        return rc;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return R3D_OK;
+}
+
+void r3d_destroy(r3d_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    r3d_buf *bufs[] = {&ctx->img_l, &ctx->img_r, &ctx->rec_l, &ctx->rec_r, &ctx->cost, &ctx->cspec, &ctx->hsum,
+                       &ctx->raw, &ctx->mins, &ctx->lrd, &ctx->out, &ctx->flags};
+    for (r3d_buf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (r3d_buf &b : ctx->cloud_bufs)
+        if (b.p) (void)hipFree(b.p);
+    if (ctx->ev_created)
+        for (int i = 0; i <= R3D_MAX_PROF; i++) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char *r3d_last_error(const r3d_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_err.c_str(); }
+
+int r3d_sync(r3d_ctx *ctx) {
+    if (!ctx) return R3D_E_BADARG;
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return R3D_OK;
+}
+
+int r3d_set_stream(r3d_ctx *ctx, void *s) {
+    if (!ctx) return R3D_E_BADARG;
+    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return R3D_OK;
+}
+void *r3d_get_stream(r3d_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int r3d_selftest(r3d_ctx *ctx) {
+    if (!ctx) return R3D_E_BADARG;
+    return r3d_selftest_run(ctx);
+}
+
+int r3d_dev_alloc(r3d_ctx *ctx, uint64_t bytes, void **out) {
+    if (!ctx || !out) return R3D_E_BADARG;
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+    if (e != hipSuccess) return r3d_fail(ctx, R3D_E_OOM, "hipMalloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e));
+    return R3D_OK;
+}
+int r3d_dev_free(r3d_ctx *ctx, void *p) {
+    if (!ctx) return R3D_E_BADARG;
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    R3D_HIP(ctx, hipFree(p));
+    return R3D_OK;
+}
+int r3d_copy_h2d(r3d_ctx *ctx, void *d, const void *h, uint64_t bytes) {
+    if (!ctx || (!d && bytes) || (!h && bytes)) return R3D_E_BADARG;
+    R3D_HIP(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return R3D_OK;
+}
+int r3d_copy_d2h(r3d_ctx *ctx, void *h, const void *d, uint64_t bytes) {
+    if (!ctx || (!d && bytes) || (!h && bytes)) return R3D_E_BADARG;
+    R3D_HIP(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return R3D_OK;
+}
+int r3d_event_create(r3d_ctx *ctx, void **out) {
+    if (!ctx || !out) return R3D_E_BADARG;
+    hipEvent_t e;
+    R3D_HIP(ctx, hipEventCreate(&e));
+    *out = (void *)e;
+    return R3D_OK;
+}
+int r3d_event_destroy(r3d_ctx *ctx, void *e) {
+    if (!ctx) return R3D_E_BADARG;
+    R3D_HIP(ctx, hipEventDestroy((hipEvent_t)e));
+    return R3D_OK;
+}
+int r3d_event_record(r3d_ctx *ctx, void *e) {
+    if (!ctx || !e) return R3D_E_BADARG;
+    R3D_HIP(ctx, hipEventRecord((hipEvent_t)e, ctx->stream));
+    return R3D_OK;
+}
+int r3d_event_elapsed_ms(r3d_ctx *ctx, void *a, void *b, float *ms) {
+    if (!ctx || !a || !b || !ms) return R3D_E_BADARG;
+    R3D_HIP(ctx, hipEventSynchronize((hipEvent_t)b));
+    R3D_HIP(ctx, hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return R3D_OK;
+}
+
+int r3d_set_profiling(r3d_ctx *ctx, int enabled) {
+    if (!ctx) return R3D_E_BADARG;
+    ctx->profiling = enabled != 0;
+    return R3D_OK;
+}
+
+int r3d_sgbm_profile(r3d_ctx *ctx, float *ms, int32_t max_slots, char *names, int32_t names_bytes) {
+    if (!ctx) return R3D_E_BADARG;
+    if (!ctx->profiling || ctx->n_ev == 0) return 0;
+    if (hipEventSynchronize(ctx->ev[ctx->n_ev]) != hipSuccess) return r3d_fail(ctx, R3D_E_HIP, "profile: event sync failed");
+    int n = ctx->n_ev < max_slots ? ctx->n_ev : max_slots;
+    size_t off = 0;
+    for (int i = 0; i < n; i++) {
+        float t = 0;
+        (void)hipEventElapsedTime(&t, ctx->ev[i], ctx->ev[i + 1]);
+        if (ms) ms[i] = t;
+        if (names) {
+            size_t len = strlen(ctx->ev_name[i]) + 1;
+            if (off + len <= (size_t)names_bytes) { memcpy(names + off, ctx->ev_name[i], len); off += len; }
+        }
+    }
+    return n;
+}
+
+int r3d_sgbm_compute_dev(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, const uint8_t *d_right, int32_t w,
+                         int32_t h, int32_t stride, int16_t *d_disp) {
+    if (!ctx) return R3D_E_BADARG;
+    return r3d_sgm_run(ctx, p, d_left, d_right, w, h, stride, d_disp);
+}
+
+int r3d_sgbm_compute(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *left, const uint8_t *right, int32_t w, int32_t h,
+                     int32_t stride, int16_t *disp) {
+    if (!ctx) return R3D_E_BADARG;
+    if (!left || !right || !disp) return r3d_fail(ctx, R3D_E_BADARG, "sgbm: null host pointer");
+    if (w <= 0 || h <= 0 || stride < w) return r3d_fail(ctx, R3D_E_BADARG, "sgbm: bad size %dx%d stride %d", w, h, stride);
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ib = (size_t)stride * h, ob = (size_t)w * h * 2;
+    int rc;
+    if ((rc = r3d_reserve(ctx, ctx->img_l, ib)) || (rc = r3d_reserve(ctx, ctx->img_r, ib)) || (rc = r3d_reserve(ctx, ctx->out, ob))) return rc;
+    R3D_HIP(ctx, hipMemcpyAsync(ctx->img_l.p, left, ib, hipMemcpyHostToDevice, ctx->stream));
+    R3D_HIP(ctx, hipMemcpyAsync(ctx->img_r.p, right, ib, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = r3d_sgm_run(ctx, p, (const uint8_t *)ctx->img_l.p, (const uint8_t *)ctx->img_r.p, w, h, stride, (int16_t *)ctx->out.p))) return rc;
+    R3D_HIP(ctx, hipMemcpyAsync(disp, ctx->out.p, ob, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return R3D_OK;
+}
+
+int r3d_sgbm_debug_fetch(r3d_ctx *ctx, int16_t *cost, int16_t *hsum, int16_t *raw) {
+    if (!ctx) return R3D_E_BADARG;
+    if (ctx->last_w == 0) return r3d_fail(ctx, R3D_E_BADARG, "debug_fetch: no sgbm call yet");
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t vol = (size_t)ctx->last_h * ctx->last_w1 * ctx->last_dp * 2;
+    if (cost) R3D_HIP(ctx, hipMemcpy(cost, ctx->cost.p, vol, hipMemcpyDeviceToHost));
+    if (hsum) R3D_HIP(ctx, hipMemcpy(hsum, ctx->hsum.p, vol, hipMemcpyDeviceToHost));
+    if (raw) R3D_HIP(ctx, hipMemcpy(raw, ctx->lrd.p, (size_t)ctx->last_w * ctx->last_h * 2, hipMemcpyDeviceToHost));
+    return R3D_OK;
+}
+
+}  // extern "C"

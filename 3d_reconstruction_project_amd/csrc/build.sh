@@ -1,0 +1,10 @@
+#!/bin/bash
+# Builds lib/libr3d_hip.so for gfx950 (cross-compiles without a GPU).  Usage: csrc/build.sh [extra hipcc flags]
+set -euo pipefail
+here="$(cd "$(dirname "$0")" && pwd)"
+out="$here/../lib"
+mkdir -p "$out"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function \
+    "$@" "$here"/api.hip "$here"/sgm.hip $(ls "$here"/cloud.hip 2>/dev/null || true) -o "$out/libr3d_hip.so"
+echo "built $out/libr3d_hip.so"

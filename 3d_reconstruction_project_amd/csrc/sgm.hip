@@ -1,0 +1,646 @@
+// sgm.hip -- semi-global block matching (3-way) for gfx950, hand-written for 64-wide wavefronts.
+//
+// Replaces cv2.StereoSGBM(mode=MODE_SGBM_3WAY).compute (reference call sites: Calib_depth/depth2.py:146-158,251
+// and the other depth*.py files); the arithmetic restated here is OpenCV's stereosgbm.cpp as pinned down in
+// oracle/sgbm3way.c (every QUIRK listed there is reproduced bit for bit).
+//
+// Data layout in HBM (all int16 unless noted; "dp" = 128 for D<=128, 256 otherwise; w1 = maxX1-minX1):
+//   rec_l/rec_r  uint2 [h][w]       per pixel: (g, g_lo, g_hi, i | i_lo, i_hi, 0, 0): prefiltered gradient, raw
+//                                   intensity and their Birchfield-Tomasi half-pixel intervals
+//   cost         [h][w1][dp]        aggregated block cost C (blockSize x blockSize box of the BT pixel cost)
+//   cspec        [3][SH2][w1][dp]   C of the first SH2 rows of stripes 1..3 (box replicated at the stripe top)
+//   hsum         [h][w1][dp]        L_left + L_right
+//   raw / mins   [h][w]             WTA disparity (x16, before LR check) and its aggregated cost
+// Lane mapping of every volume kernel: one wavefront owns ONE (row, column) disparity vector; lane l holds the
+// 2*NP consecutive disparities d = 2*NP*l .. 2*NP*l+2*NP-1 as NP packed int16x2 registers, so a wave reads or
+// writes 256*NP contiguous bytes per pixel and the d-1 / d+1 neighbours come from one DPP wave shift each way.
+#include "r3d_internal.h"
+
+namespace {
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+struct SgmGeom {
+    int W, H, minD, D, NP, minX1, maxX1, W1, SW2, SH2, P1, P2, uniq, d12, ftzero, stripe_sz, overlap, invalid;
+};
+
+constexpr int PADPK = 0x7fff7fff;  // SHRT_MAX in both halves: the d=-1 / d=D padding of every path buffer
+
+__device__ __forceinline__ s16x2 as_s(int v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ u16x2 as_u(int v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ int as_i(s16x2 v) { return __builtin_bit_cast(int, v); }
+__device__ __forceinline__ int as_i(u16x2 v) { return __builtin_bit_cast(int, v); }
+__device__ __forceinline__ int pk_add(int a, int b) { return as_i(as_s(a) + as_s(b)); }
+__device__ __forceinline__ int pk_sub(int a, int b) { return as_i(as_s(a) - as_s(b)); }
+__device__ __forceinline__ int pk_add_sat(int a, int b) { return as_i(__builtin_elementwise_add_sat(as_s(a), as_s(b))); }
+__device__ __forceinline__ int pk_min(int a, int b) { return as_i(__builtin_elementwise_min(as_s(a), as_s(b))); }
+__device__ __forceinline__ int pk_umax(int a, int b) { return as_i(__builtin_elementwise_max(as_u(a), as_u(b))); }
+__device__ __forceinline__ int pk_umin(int a, int b) { return as_i(__builtin_elementwise_min(as_u(a), as_u(b))); }
+__device__ __forceinline__ int pk_usub_sat(int a, int b) { return as_i(__builtin_elementwise_sub_sat(as_u(a), as_u(b))); }
+__device__ __forceinline__ int pk_dup(int v) { return (v & 0xffff) | (v << 16); }
+__device__ __forceinline__ int lo16(int v) { return (int)(short)(v & 0xffff); }
+__device__ __forceinline__ int hi16(int v) { return v >> 16; }
+
+// lane i receives lane i-1 (lane 0 keeps `fill`) / lane i+1 (lane 63 keeps `fill`)
+__device__ __forceinline__ int wave_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int wave_shl1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
+
+// butterfly all-reduce over the 64 lanes: every lane ends with the result (xor 1, 2 via quad_perm; 4, 8 via
+// row_half_mirror / row_mirror; 16, 32 via the gfx950 permlane swaps)
+#define R3D_BUTTERFLY(OP)                                                                   \
+    v = OP(v, (T)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false));       \
+    v = OP(v, (T)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false));       \
+    v = OP(v, (T)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false));      \
+    v = OP(v, (T)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false));      \
+    { auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); v = OP((T)r[0], (T)r[1]); } \
+    { auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false); v = OP((T)r[0], (T)r[1]); }
+__device__ __forceinline__ int wave_allmin_i32(int v) { typedef int T; R3D_BUTTERFLY(min) return v; }
+__device__ __forceinline__ unsigned wave_allmin_u32(unsigned v) { typedef unsigned T; R3D_BUTTERFLY(min) return v; }
+__device__ __forceinline__ int wave_allmax_i32(int v) { typedef int T; R3D_BUTTERFLY(max) return v; }
+
+// ---------------------------------------------------------------------------------------------------------
+// One SGM path step for one disparity vector (OpenCV accumulateCostsLeftTop / accumulateCostsRight):
+//   L[d] = C[d] + min(Lp[d], Lp[d-1]+P1, Lp[d+1]+P1, minp+P2) - (minp+P2),   Lp[-1] = Lp[D] = SHRT_MAX
+// P holds Lp on entry and L on exit; minp (wave-uniform) holds min_d Lp on entry and min_d L on exit.
+// The packed adds cannot overflow inside the envelope checked on the host (C <= 16383, P2 <= 16383); the
+// +P1 on the SHRT_MAX padding saturates (v_pk_add_i16 clamp), which never wins the min.
+template <int NP>
+__device__ __forceinline__ void sgm_step(int (&P)[NP], int &minp, const int (&C)[NP], int P1pk, int P2, bool lane_valid) {
+    const int mp2 = pk_dup(minp + P2);
+    const int up = wave_shr1(P[NP - 1], PADPK);  // lane-1's highest pair
+    const int dn = wave_shl1(P[0], PADPK);       // lane+1's lowest pair
+    int Q[NP];
+    int m32 = 0x7fff;
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        const int below = j == 0 ? up : P[j - 1];
+        const int above = j == NP - 1 ? dn : P[j + 1];
+        const int A = __builtin_amdgcn_alignbit(P[j], below, 16);  // (L[d-1]) for both halves
+        const int B = __builtin_amdgcn_alignbit(above, P[j], 16);  // (L[d+1]) for both halves
+        const int nb = pk_add_sat(pk_min(A, B), P1pk);
+        const int m = pk_min(pk_min(P[j], mp2), nb);
+        int q = pk_add(C[j], pk_sub(m, mp2));
+        q = lane_valid ? q : PADPK;
+        Q[j] = q;
+        m32 = min(m32, min(lo16(q), hi16(q)));
+    }
+#pragma unroll
+    for (int j = 0; j < NP; j++) P[j] = Q[j];
+    minp = wave_allmin_i32(m32);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_prefilter: per pixel, both images: clipped x-Sobel (calcPixelCostBT's `tab` lookup), raw intensity, and the
+// half-pixel min/max intervals of both.  QUIRK: columns 0 and w-1 of both channels read ftzero.
+__device__ __forceinline__ int px_grad(const uint8_t *img, int ld, int W, int H, int x, int y, int ft) {
+    if (x <= 0 || x >= W - 1) return ft;
+    const uint8_t *r = img + (size_t)y * ld, *a = img + (size_t)max(y - 1, 0) * ld, *b = img + (size_t)min(y + 1, H - 1) * ld;
+    int s = ((int)r[x + 1] - (int)r[x - 1]) * 2 + ((int)a[x + 1] - (int)a[x - 1]) + ((int)b[x + 1] - (int)b[x - 1]);
+    return min(max(s, -ft), ft) + ft;
+}
+__device__ __forceinline__ int px_raw(const uint8_t *img, int ld, int W, int x, int y, int ft) {
+    return (x <= 0 || x >= W - 1) ? ft : (int)img[(size_t)y * ld + x];
+}
+__device__ __forceinline__ void bt_interval(int vm, int v, int vp, bool has_m, bool has_p, int &lo, int &hi) {
+    int l = has_m ? (v + vm) / 2 : v, r = has_p ? (v + vp) / 2 : v;
+    lo = min(min(l, r), v);
+    hi = max(max(l, r), v);
+}
+__global__ void __launch_bounds__(256) k_prefilter(const uint8_t *__restrict__ L, const uint8_t *__restrict__ R, int ld,
+                                                   int W, int H, int ft, uint2 *__restrict__ recL, uint2 *__restrict__ recR) {
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const uint8_t *img = blockIdx.z == 0 ? L : R;
+    uint2 *rec = blockIdx.z == 0 ? recL : recR;
+    const bool hm = x > 0, hp = x < W - 1;
+    int gm = hm ? px_grad(img, ld, W, H, x - 1, y, ft) : 0, g = px_grad(img, ld, W, H, x, y, ft), gp = hp ? px_grad(img, ld, W, H, x + 1, y, ft) : 0;
+    int im = hm ? px_raw(img, ld, W, x - 1, y, ft) : 0, i = px_raw(img, ld, W, x, y, ft), ip = hp ? px_raw(img, ld, W, x + 1, y, ft) : 0;
+    int g0, g1, i0, i1;
+    bt_interval(gm, g, gp, hm, hp, g0, g1);
+    bt_interval(im, i, ip, hm, hp, i0, i1);
+    rec[(size_t)y * W + x] = make_uint2((unsigned)g | (g0 << 8) | (g1 << 16) | (i << 24), (unsigned)i0 | (i1 << 8));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_cost: Birchfield-Tomasi pixel cost -> blockSize x blockSize box sum -> cost volume.
+// Workgroup = 8 waves, one tile of TX cost columns, marching down a band of rows 8 at a time:
+//   phase 1: wave w computes the horizontal box sums hsum(x, r) of image row r for the tile (sliding along x;
+//            the last 2*SW2+1 pixel-cost vectors live in a per-wave LDS ring) into an LDS ring of rows;
+//   phase 2: wave w sums the 2*SH2+1 ring rows around output row y and streams C(y, tile) to HBM
+//            (TX*256*NP contiguous bytes per wave).
+// Replicated borders: columns clamp to [0, w1) in COST coordinates, rows clamp to [clampTop, h-1].
+__device__ __forceinline__ int bt_cost_pk(int U, int U0, int U1, int V, int V0, int V1) {
+    int c0 = pk_umax(pk_usub_sat(U, V1), pk_usub_sat(V0, U));
+    int c1 = pk_umax(pk_usub_sat(V, U1), pk_usub_sat(U0, V));
+    return pk_umin(c0, c1);
+}
+
+constexpr int COST_NW = 8;
+
+template <int NP>
+__global__ void __launch_bounds__(COST_NW * 64) k_cost(const uint2 *__restrict__ recL, const uint2 *__restrict__ recR, SgmGeom g,
+                                                       int *__restrict__ cvol, int *__restrict__ cspec, int TX, int BAND,
+                                                       int nMain, int RING) {
+    extern __shared__ int lds[];
+    constexpr int NPW = NP * 64;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int NR = COST_NW + 2 * g.SH2;
+    int *hs = lds;                                          // [NR][TX][NPW]
+    int *ring = lds + (size_t)NR * TX * NPW + w * RING * NPW;  // per wave [RING][NPW]
+    const int xt0 = blockIdx.x * TX;
+    const size_t rowWords = (size_t)g.W1 * NPW;
+    int y0, y1, clampTop;
+    int *obase;  // output row y lives at obase + (y - y0) * rowWords
+    if ((int)blockIdx.y < nMain) {
+        y0 = blockIdx.y * BAND;
+        y1 = min(y0 + BAND, g.H);
+        clampTop = 0;
+        obase = cvol + (size_t)y0 * rowWords;
+    } else {
+        const int n = blockIdx.y - nMain + 1;
+        const int ss = max(min(n * g.stripe_sz - g.overlap, g.H), 0);
+        y0 = ss;
+        y1 = min(ss + g.SH2, g.H);
+        clampTop = ss;
+        obase = cspec + (size_t)(n - 1) * g.SH2 * rowWords;
+    }
+    const int ntx = min(TX, g.W1 - xt0);
+    int have = max(y0 - g.SH2, clampTop) - 1;
+    for (int yb = y0; yb < y1; yb += COST_NW) {
+        const int need = min(yb + COST_NW - 1 + g.SH2, g.H - 1);
+        // ---- phase 1
+        for (int r = have + 1 + w; r <= need; r += COST_NW) {
+            const uint2 *lrow = recL + (size_t)r * g.W;
+            const uint2 *rrow = recR + (size_t)r * g.W;
+            int *hrow = hs + (size_t)(r % NR) * TX * NPW;
+            int acc[NP];
+#pragma unroll
+            for (int j = 0; j < NP; j++) acc[j] = 0;
+            const int kstart = xt0 - g.SW2, kend = xt0 + ntx - 1 + g.SW2;
+            for (int k = kstart; k <= kend; ++k) {
+                const int xc = min(max(k, 0), g.W1 - 1);
+                const int x = xc + g.minX1;
+                const uint2 lr = lrow[x];  // wave-uniform
+                const int Ug = (lr.x & 255) * 0x10001, Ug0 = ((lr.x >> 8) & 255) * 0x10001, Ug1 = ((lr.x >> 16) & 255) * 0x10001;
+                const int Ui = (lr.x >> 24) * 0x10001, Ui0 = (lr.y & 255) * 0x10001, Ui1 = ((lr.y >> 8) & 255) * 0x10001;
+                const int rbase = x - g.minD - 2 * NP * lane;  // right column of this lane's lowest disparity
+                const int slot = (k - kstart) & (RING - 1);
+                const int oslot = (k - 2 * g.SW2 - kstart) & (RING - 1);
+                const bool emit = k >= xt0 + g.SW2;
+#pragma unroll
+                for (int j = 0; j < NP; j++) {
+                    const int ra = min(max(rbase - 2 * j, 0), g.W - 1);      // d even  (low half)
+                    const int rb = min(max(rbase - 2 * j - 1, 0), g.W - 1);  // d odd   (high half)
+                    const uint2 A = rrow[ra], B = rrow[rb];
+                    const int Vg = __builtin_amdgcn_perm(B.x, A.x, 0x0c040c00), Vg0 = __builtin_amdgcn_perm(B.x, A.x, 0x0c050c01);
+                    const int Vg1 = __builtin_amdgcn_perm(B.x, A.x, 0x0c060c02), Vi = __builtin_amdgcn_perm(B.x, A.x, 0x0c070c03);
+                    const int Vi0 = __builtin_amdgcn_perm(B.y, A.y, 0x0c040c00), Vi1 = __builtin_amdgcn_perm(B.y, A.y, 0x0c050c01);
+                    const int cg = bt_cost_pk(Ug, Ug0, Ug1, Vg, Vg0, Vg1);
+                    const int ci = bt_cost_pk(Ui, Ui0, Ui1, Vi, Vi0, Vi1);
+                    const int pix = pk_add(cg, (ci >> 2) & 0x3fff3fff);  // gradient + (intensity >> 2), both halves
+                    acc[j] = pk_add(acc[j], pix);
+                    ring[slot * NPW + lane * NP + j] = pix;
+                    if (emit) {
+                        hrow[(k - g.SW2 - xt0) * NPW + lane * NP + j] = acc[j];
+                        acc[j] = pk_sub(acc[j], ring[oslot * NPW + lane * NP + j]);
+                    }
+                }
+            }
+        }
+        have = need;
+        __syncthreads();
+        // ---- phase 2
+        const int yo = yb + w;
+        if (yo < y1) {
+            int *orow = obase + (size_t)(yo - y0) * rowWords + (size_t)xt0 * NPW;
+            for (int xt = 0; xt < ntx; ++xt) {
+                int s[NP];
+#pragma unroll
+                for (int j = 0; j < NP; j++) s[j] = 0;
+                for (int dy = -g.SH2; dy <= g.SH2; ++dy) {
+                    const int rr = min(max(yo + dy, clampTop), g.H - 1);
+                    const int *h = hs + ((size_t)(rr % NR) * TX + xt) * NPW + lane * NP;
+#pragma unroll
+                    for (int j = 0; j < NP; j++) s[j] = pk_add(s[j], h[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < NP; j++) orow[xt * NPW + lane * NP + j] = s[j];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_hscan: one wave per image row: forward scan writes L_left, backward scan adds L_right in place.
+template <int NP, int U>
+__device__ __forceinline__ void load_run(int (&buf)[U][NP], const int *__restrict__ row, int x0, int dir, int W1, int NPW) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int x = min(max(x0 + dir * u, 0), W1 - 1);
+#pragma unroll
+        for (int j = 0; j < NP; j++) buf[u][j] = row[(size_t)x * NPW + j];
+    }
+}
+
+template <int NP>
+__global__ void __launch_bounds__(64) k_hscan(const int *__restrict__ cvol, int *__restrict__ hvol, SgmGeom g) {
+    constexpr int NPW = NP * 64, U = 16;
+    const int lane = threadIdx.x, y = blockIdx.x;
+    const int *crow = cvol + (size_t)y * g.W1 * NPW + lane * NP;
+    int *hrow = hvol + (size_t)y * g.W1 * NPW + lane * NP;
+    const bool valid = 2 * NP * lane < g.D;
+    const int P1pk = pk_dup(g.P1), W1 = g.W1;
+    int P[NP], minp = 0;
+    int cA[U][NP], cB[U][NP], lA[U][NP], lB[U][NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) P[j] = valid ? 0 : PADPK;
+
+#define HS_FWD(buf, xb)                                                    \
+    _Pragma("unroll") for (int u = 0; u < U; u++) {                        \
+        const int x = (xb) + u;                                            \
+        if (x < W1) {                                                      \
+            sgm_step<NP>(P, minp, buf[u], P1pk, g.P2, valid);              \
+            _Pragma("unroll") for (int j = 0; j < NP; j++) hrow[(size_t)x * NPW + j] = P[j]; \
+        }                                                                  \
+    }
+    load_run<NP, U>(cA, crow, 0, 1, W1, NPW);
+    for (int x0 = 0; x0 < W1; x0 += 2 * U) {
+        load_run<NP, U>(cB, crow, x0 + U, 1, W1, NPW);
+        HS_FWD(cA, x0)
+        load_run<NP, U>(cA, crow, x0 + 2 * U, 1, W1, NPW);
+        HS_FWD(cB, x0 + U)
+    }
+#undef HS_FWD
+    // backward: the L_left values written above are read back by the same lanes (same wave => program order)
+    minp = 0;
+#pragma unroll
+    for (int j = 0; j < NP; j++) P[j] = valid ? 0 : PADPK;
+#define HS_BWD(cb, lb, xb)                                                 \
+    _Pragma("unroll") for (int u = 0; u < U; u++) {                        \
+        const int x = (xb)-u;                                              \
+        if (x >= 0) {                                                      \
+            sgm_step<NP>(P, minp, cb[u], P1pk, g.P2, valid);               \
+            _Pragma("unroll") for (int j = 0; j < NP; j++) hrow[(size_t)x * NPW + j] = pk_add(lb[u][j], P[j]); \
+        }                                                                  \
+    }
+    load_run<NP, U>(cA, crow, W1 - 1, -1, W1, NPW);
+    load_run<NP, U>(lA, hrow, W1 - 1, -1, W1, NPW);
+    for (int x0 = W1 - 1; x0 >= 0; x0 -= 2 * U) {
+        load_run<NP, U>(cB, crow, x0 - U, -1, W1, NPW);
+        load_run<NP, U>(lB, hrow, x0 - U, -1, W1, NPW);
+        HS_BWD(cA, lA, x0)
+        load_run<NP, U>(cA, crow, x0 - 2 * U, -1, W1, NPW);
+        load_run<NP, U>(lA, hrow, x0 - 2 * U, -1, W1, NPW);
+        HS_BWD(cB, lB, x0 - U)
+    }
+#undef HS_BWD
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_vscan: one wave per (stripe, CPW adjacent cost columns): marches down the stripe's rows keeping the CPW
+// L_top vectors in registers (CPW independent dependency chains => ILP), adds L_left+L_right, and does the
+// winner-take-all, uniqueness test and sub-pixel interpolation of every output row.
+template <int NP>
+__device__ __forceinline__ int read_s(const int (&S)[NP], int d) {  // d wave-uniform
+    const int l = __builtin_amdgcn_readfirstlane(d / (2 * NP));
+    int v;
+    if (NP == 1) v = __builtin_amdgcn_readlane(S[0], l);
+    else {
+        const int v0 = __builtin_amdgcn_readlane(S[0], l), v1 = __builtin_amdgcn_readlane(S[NP - 1], l);
+        v = ((d >> 1) & 1) ? v1 : v0;
+    }
+    return (d & 1) ? hi16(v) : lo16(v);
+}
+
+template <int NP, int CPW>
+__global__ void __launch_bounds__(64) k_vscan(const int *__restrict__ cvol, const int *__restrict__ cspec,
+                                              const int *__restrict__ hvol, SgmGeom g, int16_t *__restrict__ raw,
+                                              int16_t *__restrict__ mins) {
+    constexpr int NPW = NP * 64;
+    const int lane = threadIdx.x, n = blockIdx.y, xc0 = blockIdx.x * CPW;
+    const size_t rowWords = (size_t)g.W1 * NPW;
+    const int src_start = max(min(n * g.stripe_sz - g.overlap, g.H), 0);
+    const int src_end = min((n + 1) * g.stripe_sz, g.H);
+    const int out_start = min(n * g.stripe_sz, g.H);
+    if (src_start >= src_end) return;  // stripe lies below the image (tiny h)
+    const bool valid = 2 * NP * lane < g.D;
+    const int P1pk = pk_dup(g.P1);
+    int P[CPW][NP], minp[CPW], col[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; c++) {
+        minp[c] = 0;
+        col[c] = min(xc0 + c, g.W1 - 1) * NPW + lane * NP;
+#pragma unroll
+        for (int j = 0; j < NP; j++) P[c][j] = valid ? 0 : PADPK;
+    }
+    int cc[CPW][NP], hh[CPW][NP], cn[CPW][NP], hn[CPW][NP];
+    auto crow_of = [&](int y) -> const int * {
+        return (n > 0 && y < src_start + g.SH2) ? cspec + ((size_t)(n - 1) * g.SH2 + (y - src_start)) * rowWords
+                                                 : cvol + (size_t)y * rowWords;
+    };
+    auto load_row = [&](int y, int (&cb)[CPW][NP], int (&hb)[CPW][NP]) {
+        const int yy = min(y, src_end - 1);
+        const int *cr = crow_of(yy);
+        const int *hr = hvol + (size_t)yy * rowWords;
+        const bool wantH = yy >= out_start;
+#pragma unroll
+        for (int c = 0; c < CPW; c++)
+#pragma unroll
+            for (int j = 0; j < NP; j++) {
+                cb[c][j] = cr[col[c] + j];
+                hb[c][j] = wantH ? hr[col[c] + j] : 0;
+            }
+    };
+    auto process = [&](int y, int (&cb)[CPW][NP], int (&hb)[CPW][NP]) {
+#pragma unroll
+        for (int c = 0; c < CPW; c++) sgm_step<NP>(P[c], minp[c], cb[c], P1pk, g.P2, valid);
+        if (y < out_start) return;
+        int odisp = g.invalid, omin = 0x7fff;
+#pragma unroll
+        for (int c = 0; c < CPW; c++) {
+            int S[NP];
+            unsigned key = 0xffffffffu;
+#pragma unroll
+            for (int j = 0; j < NP; j++) {
+                S[j] = pk_add_sat(hb[c][j], P[c][j]);
+                const int d0 = 2 * NP * lane + 2 * j;
+                const unsigned k0 = ((unsigned)(lo16(S[j]) + 32768) << 8) | (unsigned)d0;
+                const unsigned k1 = ((unsigned)(hi16(S[j]) + 32768) << 8) | (unsigned)(d0 + 1);
+                key = min(key, min(k0, k1));
+            }
+            key = valid ? key : 0xffffffffu;
+            key = wave_allmin_u32(key);
+            const int best = __builtin_amdgcn_readfirstlane((int)(key & 255u));
+            const int minS = __builtin_amdgcn_readfirstlane((int)(key >> 8) - 32768);
+            bool bad = false;
+            if (g.uniq > 0) {
+                bool lb = false;
+#pragma unroll
+                for (int j = 0; j < NP; j++) {
+                    const int d0 = 2 * NP * lane + 2 * j;
+                    lb |= (lo16(S[j]) * (100 - g.uniq) < minS * 100) && (abs(d0 - best) > 1);
+                    lb |= (hi16(S[j]) * (100 - g.uniq) < minS * 100) && (abs(d0 + 1 - best) > 1);
+                }
+                bad = __any(lb && valid);
+            }
+            int dsp = g.invalid;
+            if (!bad) {
+                if (0 < best && best < g.D - 1) {
+                    const int sm = read_s<NP>(S, best - 1), sp = read_s<NP>(S, best + 1);
+                    const int den = max(sm + sp - 2 * minS, 1);
+                    dsp = best * 16 + ((sm - sp) * 16 + den) / (den * 2);
+                } else
+                    dsp = best * 16;
+                dsp += g.minD * 16;
+            }
+            if (lane == c && xc0 + c < g.W1) { odisp = dsp; omin = minS; }
+        }
+        if (lane < CPW && xc0 + lane < g.W1) {
+            const size_t o = (size_t)y * g.W + g.minX1 + xc0 + lane;
+            raw[o] = (int16_t)odisp;
+            mins[o] = (int16_t)omin;
+        }
+    };
+    load_row(src_start, cc, hh);
+    for (int y = src_start; y < src_end; y += 2) {
+        load_row(y + 1, cn, hn);
+        process(y, cc, hh);
+        load_row(y + 2, cc, hh);
+        if (y + 1 < src_end) process(y + 1, cn, hn);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_lrcheck: per row: rebuild OpenCV's disp2 / disp2cost scatter (lowest cost wins, among equal costs the
+// LARGEST x, because the original sweeps x right-to-left with a strict '>') with one LDS atomicMin on the key
+// (cost+32768)<<16 | (w-1-x), then apply the two-sided disp12MaxDiff test.  Output covers all w columns.
+__global__ void __launch_bounds__(256) k_lrcheck(const int16_t *__restrict__ raw, const int16_t *__restrict__ mins, SgmGeom g,
+                                                 int16_t *__restrict__ out) {
+    extern __shared__ unsigned keys[];
+    const int y = blockIdx.x, W = g.W;
+    const int16_t *r = raw + (size_t)y * W, *m = mins + (size_t)y * W;
+    for (int x = threadIdx.x; x < W; x += 256) keys[x] = 0xffffffffu;
+    __syncthreads();
+    for (int x = g.minX1 + threadIdx.x; x < g.maxX1; x += 256) {
+        const int d1 = r[x];
+        if (d1 == g.invalid) continue;
+        const int d = (d1 + 7) >> 4;  // best + minD (sub-pixel offset lies in [-7, 8])
+        const int x2 = x - d;
+        atomicMin(&keys[x2], ((unsigned)((int)m[x] + 32768) << 16) | (unsigned)(W - 1 - x));
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < W; x += 256) {
+        int d1 = g.invalid;
+        if (x >= g.minX1 && x < g.maxX1) {
+            d1 = r[x];
+            if (d1 != g.invalid) {
+                const int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
+                const int _x = x - _d, x_ = x - d_;
+                bool f1 = false, f2 = false;
+                if (0 <= _x && _x < W && keys[_x] != 0xffffffffu) {
+                    const int d2 = (W - 1 - (int)(keys[_x] & 0xffffu)) - _x;  // disp2[_x] (>= minD by construction)
+                    f1 = abs(d2 - _d) > g.d12;
+                }
+                if (0 <= x_ && x_ < W && keys[x_] != 0xffffffffu) {
+                    const int d2 = (W - 1 - (int)(keys[x_] & 0xffffu)) - x_;
+                    f2 = abs(d2 - d_) > g.d12;
+                }
+                if (f1 && f2) d1 = g.invalid;
+            }
+        }
+        out[(size_t)y * W + x] = (int16_t)d1;
+    }
+}
+
+// k_median3: medianBlur(disp, 3) on int16 with replicated borders
+__device__ __forceinline__ void cswap(int &a, int &b) { int lo = min(a, b), hi = max(a, b); a = lo; b = hi; }
+__global__ void __launch_bounds__(256) k_median3(const int16_t *__restrict__ src, int16_t *__restrict__ dst, int W, int H) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int16_t *r0 = src + (size_t)max(y - 1, 0) * W, *r1 = src + (size_t)y * W, *r2 = src + (size_t)min(y + 1, H - 1) * W;
+    const int xl = max(x - 1, 0), xr = min(x + 1, W - 1);
+    int p0 = r0[xl], p1 = r0[x], p2 = r0[xr], p3 = r1[xl], p4 = r1[x], p5 = r1[xr], p6 = r2[xl], p7 = r2[x], p8 = r2[xr];
+    cswap(p1, p2); cswap(p4, p5); cswap(p7, p8); cswap(p0, p1); cswap(p3, p4); cswap(p6, p7);
+    cswap(p1, p2); cswap(p4, p5); cswap(p7, p8); cswap(p0, p3); cswap(p5, p8); cswap(p4, p7);
+    cswap(p3, p6); cswap(p1, p4); cswap(p2, p5); cswap(p4, p7); cswap(p4, p2); cswap(p6, p4);
+    cswap(p4, p2);
+    dst[(size_t)y * W + x] = (int16_t)p4;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_selftest: checks the cross-lane building blocks against their definition.
+__global__ void __launch_bounds__(64) k_selftest(int *out) {
+    const int lane = threadIdx.x;
+    int bad = 0;
+    const int v = (lane * 37 + 11) % 101 - 50;
+    if (wave_shr1(v, -777) != (lane == 0 ? -777 : ((lane - 1) * 37 + 11) % 101 - 50)) bad |= 1;
+    if (wave_shl1(v, -777) != (lane == 63 ? -777 : ((lane + 1) * 37 + 11) % 101 - 50)) bad |= 2;
+    int mn = 1 << 30, mx = -(1 << 30);
+    for (int l = 0; l < 64; l++) { int t = (l * 37 + 11) % 101 - 50; mn = min(mn, t); mx = max(mx, t); }
+    if (wave_allmin_i32(v) != mn) bad |= 4;
+    if (wave_allmax_i32(v) != mx) bad |= 8;
+    {
+        int first = 0;  // first lane holding the minimum: the WTA key relies on "smallest index wins among ties"
+        for (int l = 63; l >= 0; l--) if ((l * 37 + 11) % 101 - 50 == mn) first = l;
+        if (wave_allmin_u32((unsigned)(v + 100) << 8 | (unsigned)lane) != (((unsigned)(mn + 100) << 8) | (unsigned)first)) bad |= 16;
+    }
+    // packed helpers
+    if (pk_add_sat(0x7fff7fff, pk_dup(600)) != 0x7fff7fff) bad |= 32;
+    if (pk_min(0x00050003, (int)0xfffe0004) != (int)0xfffe0003) bad |= 64;
+    if (pk_usub_sat(0x00050003, 0x00070001) != 0x00000002) bad |= 128;
+    if (__builtin_amdgcn_alignbit(0x11112222, 0x33334444, 16) != 0x22223333) bad |= 256;
+    if (__builtin_amdgcn_perm(0xa3a2a1a0u, 0xb3b2b1b0u, 0x0c050c01) != 0x00a100b1u) bad |= 512;
+    // one sgm_step against the scalar definition, D = 128
+    {
+        int P[1] = {(((lane * 7) % 13) & 0xffff) | ((((lane * 5) % 11)) << 16)};
+        int minp = 0;
+        int allmin = wave_allmin_i32(min(lo16(P[0]), hi16(P[0])));
+        minp = allmin;
+        const int C[1] = {((lane + 3) & 0xffff) | ((2 * lane + 1) << 16)};
+        const int P1 = 3, P2 = 9;
+        // scalar reference for this lane's two disparities
+        auto Lp = [&](int d) -> int { if (d < 0 || d > 127) return 32767; int l = d >> 1; return (d & 1) ? (l * 5) % 11 : (l * 7) % 13; };
+        int want[2];
+        for (int h = 0; h < 2; h++) {
+            int d = 2 * lane + h;
+            int m = min(min(Lp(d), minp + P2), min(Lp(d - 1), Lp(d + 1)) + P1);
+            int c = h ? 2 * lane + 1 : lane + 3;
+            want[h] = c + m - (minp + P2);
+        }
+        sgm_step<1>(P, minp, C, pk_dup(P1), P2, true);
+        if (lo16(P[0]) != want[0] || hi16(P[0]) != want[1]) bad |= 1024;
+        int wm = wave_allmin_i32(min(want[0], want[1]));
+        if (minp != wm) bad |= 2048;
+    }
+    atomicOr(out, bad);
+}
+
+int derive_geom(r3d_ctx *ctx, const r3d_sgbm_params *p, int w, int h, SgmGeom &g) {
+    if (!p) return r3d_fail(ctx, R3D_E_BADARG, "sgbm: params is NULL");
+    if (p->mode != R3D_SGBM_MODE_3WAY)
+        return r3d_fail(ctx, R3D_E_UNSUPPORTED, "sgbm: only mode=STEREO_SGBM_MODE_SGBM_3WAY (2) is implemented, got %d", p->mode);
+    if (p->numDisparities <= 0 || p->numDisparities % 16 != 0)
+        return r3d_fail(ctx, R3D_E_BADARG, "sgbm: numDisparities must be a positive multiple of 16, got %d", p->numDisparities);
+    if (p->numDisparities > 256) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "sgbm: numDisparities > 256 not supported (got %d)", p->numDisparities);
+    if (p->blockSize < 1 || p->blockSize % 2 == 0 || p->blockSize > 11)
+        return r3d_fail(ctx, R3D_E_BADARG, "sgbm: blockSize must be odd in [1, 11], got %d", p->blockSize);
+    if (w <= 0 || h <= 0 || w > 65536) return r3d_fail(ctx, R3D_E_BADARG, "sgbm: bad image size %dx%d", w, h);
+    g.W = w; g.H = h;
+    g.minD = p->minDisparity; g.D = p->numDisparities;
+    g.NP = g.D <= 128 ? 1 : 2;
+    const int maxD = g.minD + g.D;
+    g.minX1 = maxD > 0 ? maxD : 0;
+    g.maxX1 = w + (g.minD < 0 ? g.minD : 0);
+    g.W1 = g.maxX1 - g.minX1;
+    if (g.W1 <= 0) return r3d_fail(ctx, R3D_E_BADARG, "sgbm: image width %d too small for disparity range [%d, %d)", w, g.minD, maxD);
+    g.SW2 = g.SH2 = p->blockSize / 2;
+    g.P1 = p->P1 > 0 ? p->P1 : 2;
+    g.P2 = p->P2 > 0 ? p->P2 : 5;
+    if (g.P2 < g.P1 + 1) g.P2 = g.P1 + 1;
+    g.uniq = p->uniquenessRatio >= 0 ? p->uniquenessRatio : 10;
+    g.d12 = p->disp12MaxDiff > 0 ? p->disp12MaxDiff : 1;
+    g.ftzero = (p->preFilterCap > 15 ? p->preFilterCap : 15) | 1;
+    g.stripe_sz = (h + 3) / 4;
+    g.overlap = (p->blockSize / 2 + 1) + (g.stripe_sz + 9) / 10;
+    g.invalid = (g.minD - 1) * 16;
+    // exact-int16 envelope (DESIGN.md "arithmetic envelope"): no packed add may wrap
+    const long cmax = (long)p->blockSize * p->blockSize * (2L * g.ftzero + 63);
+    if (cmax > 16383 || g.P2 > 16383 || g.ftzero > 127)
+        return r3d_fail(ctx, R3D_E_UNSUPPORTED,
+                        "sgbm: blockSize=%d preFilterCap=%d P2=%d leave the exact int16 envelope (max block cost %ld > 16383 or P2 > 16383)",
+                        p->blockSize, p->preFilterCap, g.P2, cmax);
+    if ((long)g.minD * 16 - 16 < -32768 || ((long)maxD) * 16 > 32767)
+        return r3d_fail(ctx, R3D_E_BADARG, "sgbm: disparity range [%d, %d) does not fit the x16 int16 output", g.minD, maxD);
+    return R3D_OK;
+}
+
+}  // namespace
+
+int r3d_selftest_run(r3d_ctx *ctx) {
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc = r3d_reserve(ctx, ctx->flags, 256)) return rc;
+    R3D_HIP(ctx, hipMemsetAsync(ctx->flags.p, 0, 4, ctx->stream));
+    k_selftest<<<1, 64, 0, ctx->stream>>>((int *)ctx->flags.p);
+    R3D_HIP(ctx, hipGetLastError());
+    int bad = -1;
+    R3D_HIP(ctx, hipMemcpyAsync(&bad, ctx->flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad != 0) return r3d_fail(ctx, R3D_E_HIP, "selftest: cross-lane primitive mismatch, mask=0x%x", bad);
+    return R3D_OK;
+}
+
+int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, const uint8_t *d_right, int w, int h,
+                int stride, int16_t *d_disp) {
+    SgmGeom g;
+    if (int rc = derive_geom(ctx, p, w, h, g)) return rc;
+    if (!d_left || !d_right || !d_disp) return r3d_fail(ctx, R3D_E_BADARG, "sgbm: null image pointer");
+    if (stride < w) return r3d_fail(ctx, R3D_E_BADARG, "sgbm: stride %d < width %d", stride, w);
+    if (p->speckleWindowSize > 0)
+        return r3d_fail(ctx, R3D_E_UNSUPPORTED, "sgbm: speckleWindowSize > 0 (filterSpeckles) is not implemented yet");
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    const int NPW = g.NP * 64;
+    const size_t npix = (size_t)w * h;
+    const size_t rowBytes = (size_t)g.W1 * NPW * 4;
+    const size_t volBytes = rowBytes * h;
+    int rc;
+    if ((rc = r3d_reserve(ctx, ctx->rec_l, npix * 8))) return rc;
+    if ((rc = r3d_reserve(ctx, ctx->rec_r, npix * 8))) return rc;
+    if ((rc = r3d_reserve(ctx, ctx->cost, volBytes))) return rc;
+    if ((rc = r3d_reserve(ctx, ctx->cspec, rowBytes * 3 * (g.SH2 > 0 ? g.SH2 : 1)))) return rc;
+    if ((rc = r3d_reserve(ctx, ctx->hsum, volBytes))) return rc;
+    if ((rc = r3d_reserve(ctx, ctx->raw, npix * 2))) return rc;
+    if ((rc = r3d_reserve(ctx, ctx->mins, npix * 2))) return rc;
+    if ((rc = r3d_reserve(ctx, ctx->lrd, npix * 2))) return rc;
+    ctx->last_w = w; ctx->last_h = h; ctx->last_w1 = g.W1; ctx->last_dp = NPW * 2;
+    hipStream_t st = ctx->stream;
+    r3d_prof_begin(ctx);
+
+    r3d_prof_mark(ctx, "prefilter");
+    k_prefilter<<<dim3((w + 255) / 256, h, 2), 256, 0, st>>>(d_left, d_right, stride, w, h, g.ftzero, (uint2 *)ctx->rec_l.p, (uint2 *)ctx->rec_r.p);
+    R3D_HIP(ctx, hipGetLastError());
+
+    {
+        r3d_prof_mark(ctx, "cost");
+        const int TX = 16, BAND = 64;
+        int RING = 8;
+        while (RING < 2 * g.SW2 + 2) RING *= 2;
+        const int NR = COST_NW + 2 * g.SH2;
+        const size_t lds = ((size_t)NR * TX + (size_t)COST_NW * RING) * NPW * 4;
+        const int nMain = (h + BAND - 1) / BAND;
+        const int nSpec = g.SH2 > 0 ? 3 : 0;
+        dim3 grid((g.W1 + TX - 1) / TX, nMain + nSpec);
+        if (g.NP == 1) {
+            R3D_HIP(ctx, hipFuncSetAttribute((const void *)k_cost<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            k_cost<1><<<grid, COST_NW * 64, lds, st>>>((const uint2 *)ctx->rec_l.p, (const uint2 *)ctx->rec_r.p, g, (int *)ctx->cost.p, (int *)ctx->cspec.p, TX, BAND, nMain, RING);
+        } else {
+            R3D_HIP(ctx, hipFuncSetAttribute((const void *)k_cost<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            k_cost<2><<<grid, COST_NW * 64, lds, st>>>((const uint2 *)ctx->rec_l.p, (const uint2 *)ctx->rec_r.p, g, (int *)ctx->cost.p, (int *)ctx->cspec.p, TX, BAND, nMain, RING);
+        }
+        R3D_HIP(ctx, hipGetLastError());
+    }
+    r3d_prof_mark(ctx, "hscan");
+    if (g.NP == 1) k_hscan<1><<<h, 64, 0, st>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, g);
+    else k_hscan<2><<<h, 64, 0, st>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, g);
+    R3D_HIP(ctx, hipGetLastError());
+
+    r3d_prof_mark(ctx, "vscan_wta");
+    // raw must read INVALID wherever the scan does not write (columns outside [minX1, maxX1))
+    {
+        constexpr int CPW = 8;
+        dim3 grid((g.W1 + CPW - 1) / CPW, 4);
+        if (g.NP == 1) k_vscan<1, CPW><<<grid, 64, 0, st>>>((const int *)ctx->cost.p, (const int *)ctx->cspec.p, (const int *)ctx->hsum.p, g, (int16_t *)ctx->raw.p, (int16_t *)ctx->mins.p);
+        else k_vscan<2, CPW><<<grid, 64, 0, st>>>((const int *)ctx->cost.p, (const int *)ctx->cspec.p, (const int *)ctx->hsum.p, g, (int16_t *)ctx->raw.p, (int16_t *)ctx->mins.p);
+        R3D_HIP(ctx, hipGetLastError());
+    }
+    r3d_prof_mark(ctx, "lrcheck");
+    k_lrcheck<<<h, 256, (size_t)w * 4, st>>>((const int16_t *)ctx->raw.p, (const int16_t *)ctx->mins.p, g, (int16_t *)ctx->lrd.p);
+    R3D_HIP(ctx, hipGetLastError());
+    r3d_prof_mark(ctx, "median3");
+    k_median3<<<dim3((w + 255) / 256, h), 256, 0, st>>>((const int16_t *)ctx->lrd.p, d_disp, w, h);
+    R3D_HIP(ctx, hipGetLastError());
+    r3d_prof_end(ctx);
+    return R3D_OK;
+}
