@@ -35,6 +35,26 @@ int r3d_reserve(r3d_ctx *ctx, r3d_buf &b, size_t bytes) {
     return R3D_OK;
 }
 
+void r3d_prof_harvest(r3d_ctx *ctx, r3d_prof_set &ps) {
+    ps.pending = false;
+    if (ps.n == 0 || hipEventSynchronize(ps.ev[ps.n]) != hipSuccess) return;
+    for (int i = 0; i < ps.n; i++) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, ps.ev[i], ps.ev[i + 1]) != hipSuccess) continue;
+        int k = 0;
+        while (k < ctx->n_acc && strcmp(ctx->acc_name[k], ps.name[i]) != 0) k++;
+        if (k == ctx->n_acc) {
+            if (ctx->n_acc >= R3D_MAX_PROF) continue;
+            ctx->acc_name[k] = ps.name[i];
+            ctx->acc_ms[k] = 0;
+            ctx->acc_cnt[k] = 0;
+            ctx->n_acc++;
+        }
+        ctx->acc_ms[k] += t;
+        ctx->acc_cnt[k]++;
+    }
+}
+
 extern "C" {
 
 int r3d_init(int device, r3d_ctx **out) {
@@ -74,7 +94,8 @@ void r3d_destroy(r3d_ctx *ctx) {
     for (r3d_buf &b : ctx->cloud_bufs)
         if (b.p) (void)hipFree(b.p);
     if (ctx->ev_created)
-        for (int i = 0; i <= R3D_MAX_PROF; i++) (void)hipEventDestroy(ctx->ev[i]);
+        for (auto &ps : ctx->prof)
+            for (int i = 0; i <= R3D_MAX_PROF; i++) (void)hipEventDestroy(ps.ev[i]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -156,19 +177,18 @@ int r3d_set_profiling(r3d_ctx *ctx, int enabled) {
 
 int r3d_sgbm_profile(r3d_ctx *ctx, float *ms, int32_t max_slots, char *names, int32_t names_bytes) {
     if (!ctx) return R3D_E_BADARG;
-    if (!ctx->profiling || ctx->n_ev == 0) return 0;
-    if (hipEventSynchronize(ctx->ev[ctx->n_ev]) != hipSuccess) return r3d_fail(ctx, R3D_E_HIP, "profile: event sync failed");
-    int n = ctx->n_ev < max_slots ? ctx->n_ev : max_slots;
+    for (auto &ps : ctx->prof)
+        if (ps.pending) r3d_prof_harvest(ctx, ps);
+    int n = ctx->n_acc < max_slots ? ctx->n_acc : max_slots;
     size_t off = 0;
     for (int i = 0; i < n; i++) {
-        float t = 0;
-        (void)hipEventElapsedTime(&t, ctx->ev[i], ctx->ev[i + 1]);
-        if (ms) ms[i] = t;
+        if (ms) ms[i] = ctx->acc_cnt[i] ? (float)(ctx->acc_ms[i] / ctx->acc_cnt[i]) : 0.f;
         if (names) {
-            size_t len = strlen(ctx->ev_name[i]) + 1;
-            if (off + len <= (size_t)names_bytes) { memcpy(names + off, ctx->ev_name[i], len); off += len; }
+            size_t len = strlen(ctx->acc_name[i]) + 1;
+            if (off + len <= (size_t)names_bytes) { memcpy(names + off, ctx->acc_name[i], len); off += len; }
         }
     }
+    ctx->n_acc = 0;
     return n;
 }
 

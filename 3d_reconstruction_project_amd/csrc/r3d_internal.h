@@ -14,6 +14,14 @@ struct r3d_buf {
 };
 
 #define R3D_MAX_PROF 16
+#define R3D_PROF_SETS 4
+
+struct r3d_prof_set {
+    hipEvent_t ev[R3D_MAX_PROF + 1] = {};
+    const char *name[R3D_MAX_PROF] = {};
+    int n = 0;
+    bool pending = false;
+};
 
 struct r3d_ctx {
     int device = 0;
@@ -25,11 +33,14 @@ struct r3d_ctx {
     r3d_buf img_l, img_r, rec_l, rec_r, cost, cspec, hsum, raw, mins, lrd, out, flags;
     // geometry of the last sgbm call (for debug fetch)
     int last_w = 0, last_h = 0, last_w1 = 0, last_dp = 0;
-    // profiling slots
-    hipEvent_t ev[R3D_MAX_PROF + 1] = {};
-    const char *ev_name[R3D_MAX_PROF] = {};
-    int n_ev = 0;
+    // profiling: ring of event sets so that harvesting never stalls the stream; sums accumulate per kernel name
+    r3d_prof_set prof[R3D_PROF_SETS];
+    int prof_cur = 0;
     bool ev_created = false;
+    const char *acc_name[R3D_MAX_PROF] = {};
+    double acc_ms[R3D_MAX_PROF] = {};
+    int acc_cnt[R3D_MAX_PROF] = {};
+    int n_acc = 0;
     // cloud workspace (cloud.hip)
     std::vector<r3d_buf> cloud_bufs;
 };
@@ -46,23 +57,32 @@ int r3d_reserve(r3d_ctx *ctx, r3d_buf &b, size_t bytes);
     } while (0)
 
 // profiling helpers: record an event before each named kernel when ctx->profiling
+void r3d_prof_harvest(r3d_ctx *ctx, r3d_prof_set &ps);
 static inline void r3d_prof_begin(r3d_ctx *ctx) {
-    ctx->n_ev = 0;
     if (!ctx->profiling) return;
     if (!ctx->ev_created) {
-        for (int i = 0; i <= R3D_MAX_PROF; i++) (void)hipEventCreate(&ctx->ev[i]);
+        for (auto &ps : ctx->prof)
+            for (int i = 0; i <= R3D_MAX_PROF; i++) (void)hipEventCreate(&ps.ev[i]);
         ctx->ev_created = true;
     }
+    ctx->prof_cur = (ctx->prof_cur + 1) % R3D_PROF_SETS;
+    r3d_prof_set &ps = ctx->prof[ctx->prof_cur];
+    if (ps.pending) r3d_prof_harvest(ctx, ps);
+    ps.n = 0;
 }
 static inline void r3d_prof_mark(r3d_ctx *ctx, const char *name) {
-    if (!ctx->profiling || ctx->n_ev >= R3D_MAX_PROF) return;
-    (void)hipEventRecord(ctx->ev[ctx->n_ev], ctx->stream);
-    ctx->ev_name[ctx->n_ev] = name;
-    ctx->n_ev++;
+    if (!ctx->profiling) return;
+    r3d_prof_set &ps = ctx->prof[ctx->prof_cur];
+    if (ps.n >= R3D_MAX_PROF) return;
+    (void)hipEventRecord(ps.ev[ps.n], ctx->stream);
+    ps.name[ps.n] = name;
+    ps.n++;
 }
 static inline void r3d_prof_end(r3d_ctx *ctx) {
     if (!ctx->profiling) return;
-    (void)hipEventRecord(ctx->ev[ctx->n_ev], ctx->stream);
+    r3d_prof_set &ps = ctx->prof[ctx->prof_cur];
+    (void)hipEventRecord(ps.ev[ps.n], ctx->stream);
+    ps.pending = true;
 }
 
 // sgm.hip

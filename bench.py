@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""bench.py -- headline metric of BASELINE.json: disparity-maps/s at 8 MP (3264x2448), 128 disparities.
+
+One "step" = one full StereoSGBM(3-way).compute over one synthetic rectified pair that is already resident in
+HBM (one pair per rank; weak scaling: every rank owns one view, no data-path collective inside the SGM step).
+Prints ONE JSON line on rank 0.  Launch for N>1:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, D = 3264, 2448, 128                     # BASELINE config C2
+C2_KW = dict(minDisparity=0, blockSize=5, P1=8 * 3 * 25, P2=32 * 3 * 25, disp12MaxDiff=1, uniquenessRatio=15,
+             speckleWindowSize=0, speckleRange=2, preFilterCap=63)      # Calib_depth/depth2.py:139-158
+HBM_PEAK = 8.0e12                             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+W1 = W - D
+# algorithmic bytes: whole map = 4*W*H + 4*W*H*D with int16 costs; per kernel of the current split:
+ALG_BYTES = {
+    "map": 4 * W * H + 4 * W1 * H * D,
+    "hscan": 2 * W1 * H * D,                  # the one compulsory volume WRITE (L_left + L_right)
+    "vscan_wta": 2 * W1 * H * D + 4 * W * H,  # the one compulsory volume READ + disparity/cost out
+    "cost": 2 * W * H,                        # reads both images; the cost volume itself is not algorithmic
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    r3d = importlib.import_module("3d_reconstruction_project_amd")
+    ctx = r3d.Context(local_rank)
+    L, R, _ = r3d.synth.stereo_pair(W, H, D, seed=20241008 + rank)
+    dL, dR = ctx.to_device(L), ctx.to_device(R)
+    dD = ctx.alloc(W * H * 2)
+    m = r3d.StereoSGBM_create(numDisparities=D, mode=r3d.STEREO_SGBM_MODE_SGBM_3WAY, **C2_KW)
+    m._ctx = ctx
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        m.compute_device(dL, dR, W, H, W, dD)
+    ctx.set_profiling(True)
+    ctx.sgbm_profile()                         # reset accumulators
+    barrier()
+    t0 = time.perf_counter()
+    e0, e1 = ctx.event(), ctx.event()
+    ctx.record(e0)
+    for _ in range(args.steps):
+        m.compute_device(dL, dR, W, H, W, dD)
+    ctx.record(e1)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ctx.elapsed_ms(e0, e1)
+    prof = ctx.sgbm_profile()                  # average per-kernel launch duration over the timed region (HIP events)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        value = world * args.steps / elapsed
+        dom = max(prof, key=prof.get) if prof else None
+        roofline = None
+        if dom:
+            ach = ALG_BYTES.get(dom, 0) / (prof[dom] * 1e-3) / 1e9
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if os.path.exists(tp):
+                with open(tp) as f:
+                    traffic = json.load(f).get(dom)
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK / 1e9,
+                        "unit": "GB/s", "frac": round(ach * 1e9 / HBM_PEAK, 4), "traffic": traffic,
+                        "kernel_ms": {k: round(v, 4) for k, v in prof.items()},
+                        "pipeline_frac": round(ALG_BYTES["map"] * (args.steps / (dev_ms * 1e-3)) / HBM_PEAK, 4)}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import sgbm_oracle as so            # checker timed as the CPU baseline ("port")
+            p = so.make_params(numDisparities=D, **C2_KW)
+            threads = min(4, os.cpu_count() or 1)             # OpenCV runs its 4 fixed stripes under parallel_for_
+            n = 0
+            tc = time.perf_counter()
+            while n < 3 or (time.perf_counter() - tc < 8.0 and n < 40):
+                so.compute(L, R, p, nthreads=threads)
+                n += 1
+            dt = time.perf_counter() - tc
+            cpu = {"value": round(n / dt, 3), "unit": "disparity-maps/s", "cores": threads, "kind": "port",
+                   "sample": f"{n} full 3264x2448 D=128 maps, C restatement of OpenCV StereoSGBM 3WAY "
+                             f"(oracle/sgbm3way.c, -O3 AVX2), host has {os.cpu_count()} cpus"}
+        out = {"metric": "disparity-maps/s @8MP d=128", "value": round(value, 2), "unit": "disparity-maps/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+               "config": {"workload": "C2: 3264x2448 rectified pair, numDisparities=128, blockSize=5, "
+                                      "MODE_SGBM_3WAY (depth2.py params), one pair per GPU resident in HBM",
+                          "parallelism": f"dp{world} (one view per GPU, no collective in the SGM step)"},
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

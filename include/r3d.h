@@ -80,8 +80,10 @@ int r3d_sgbm_compute(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *left
 int r3d_sgbm_compute_dev(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, const uint8_t *d_right,
                          int32_t w, int32_t h, int32_t stride, int16_t *d_disp);
 
-/* per-kernel HIP-event timing of the LAST r3d_sgbm_compute*_ call made with profiling enabled.
- * names: NUL-separated list, one entry per slot; ms: one float per slot. Returns the number of slots. */
+/* per-kernel HIP-event timing (events on the ctx stream around every kernel launch while profiling is enabled).
+ * r3d_sgbm_profile returns, and then resets, the AVERAGE launch duration per kernel over all r3d_sgbm_compute*
+ * calls since the previous r3d_sgbm_profile.  names: NUL-separated list, one entry per slot; ms: one float per
+ * slot.  Returns the number of slots.  (Events live in a 4-deep ring, so profiling never stalls the stream.) */
 int r3d_set_profiling(r3d_ctx *ctx, int enabled);
 int r3d_sgbm_profile(r3d_ctx *ctx, float *ms, int32_t max_slots, char *names, int32_t names_bytes);
 
