@@ -1,0 +1,109 @@
+"""numpy-facing wrappers of the point-cloud entry points of the C ABI (include/r3d.h).  No CPU fallback."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+_vp = ctypes.c_void_p
+_dp = ctypes.POINTER(ctypes.c_double)
+
+_lib.register({
+    "r3d_voxel_downsample": ([_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_double, _vp, _vp, _vp,
+                              ctypes.POINTER(ctypes.c_int64)], ctypes.c_int),
+    "r3d_estimate_normals": ([_vp, _vp, ctypes.c_int64, ctypes.c_double, ctypes.c_int32, _vp, _vp], ctypes.c_int),
+    "r3d_neighbor_score": ([_vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_double, _vp], ctypes.c_int),
+    "r3d_knn_graph": ([_vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_double, _vp, _vp], ctypes.c_int),
+    "r3d_transform_points": ([_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int32, _vp], ctypes.c_int),
+    "r3d_icp": ([_vp, ctypes.POINTER(_lib.IcpParams), _vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp,
+                 ctypes.POINTER(_lib.IcpStats)], ctypes.c_int),
+})
+
+P2P, P2PLANE, GICP = 0, 1, 2
+
+
+def _c(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 3)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def voxel_down_sample(points, voxel, colors=None, normals=None, ctx=None):
+    ctx = ctx or _lib.default_context()
+    p, c, n = _c(points), _c(colors), _c(normals)
+    N = len(p)
+    if N == 0:
+        return p, c, n
+    op = np.empty((N, 3))
+    oc = np.empty((N, 3)) if c is not None else None
+    on = np.empty((N, 3)) if n is not None else None
+    m = ctypes.c_int64()
+    ctx.call("r3d_voxel_downsample", _ptr(p), _ptr(c), _ptr(n), N, float(voxel), _ptr(op), _ptr(oc), _ptr(on),
+             ctypes.byref(m))
+    m = m.value
+    return op[:m].copy(), (oc[:m].copy() if oc is not None else None), (on[:m].copy() if on is not None else None)
+
+
+def estimate_normals(points, radius, max_nn, prev_normals=None, ctx=None):
+    """radius None or <= 0 -> pure kNN (KDTreeSearchParamKNN)."""
+    ctx = ctx or _lib.default_context()
+    p, pn = _c(points), _c(prev_normals)
+    out = np.empty_like(p)
+    ctx.call("r3d_estimate_normals", _ptr(p), len(p), float(radius) if radius else -1.0, int(max_nn), _ptr(pn), _ptr(out))
+    return out
+
+
+def neighbor_score(points, k=0, count_radius=0.0, ctx=None):
+    ctx = ctx or _lib.default_context()
+    p = _c(points)
+    out = np.empty(len(p))
+    ctx.call("r3d_neighbor_score", _ptr(p), len(p), int(k), float(count_radius), out.ctypes.data_as(_vp))
+    return out
+
+
+def knn_graph(points, k, radius=0.0, want_d2=True, ctx=None):
+    ctx = ctx or _lib.default_context()
+    p = _c(points)
+    k = int(min(k, len(p)))
+    nbr = np.empty((len(p), k), np.int32)
+    d2 = np.empty((len(p), k)) if want_d2 else None
+    ctx.call("r3d_knn_graph", _ptr(p), len(p), k, float(radius), nbr.ctypes.data_as(_vp), _ptr(d2))
+    return nbr, d2
+
+
+def statistical_outlier_mask(points, nb_neighbors, std_ratio, ctx=None):
+    """remove_statistical_outlier(nb_neighbors, std_ratio): keep iff score < mean + ratio * std(ddof=1)."""
+    a = neighbor_score(points, k=nb_neighbors, ctx=ctx)
+    return a < a.mean() + std_ratio * a.std(ddof=1)
+
+
+def radius_outlier_mask(points, nb_points, radius, ctx=None):
+    return neighbor_score(points, count_radius=radius, ctx=ctx) > nb_points
+
+
+def transform_points(points, T, rotate_only=False, ctx=None):
+    ctx = ctx or _lib.default_context()
+    p = _c(points)
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(4, 4)
+    out = np.empty_like(p)
+    ctx.call("r3d_transform_points", _ptr(p), len(p), _ptr(T), int(bool(rotate_only)), _ptr(out))
+    return out
+
+
+def registration(source, target, max_correspondence_distance, init=None, mode=P2P, max_iteration=30,
+                 relative_fitness=1e-6, relative_rmse=1e-6, source_normals=None, target_normals=None,
+                 gicp_epsilon=1e-3, ctx=None):
+    """registration_icp / registration_generalized_icp.  Returns dict(T, fitness, inlier_rmse, iterations, ...)."""
+    ctx = ctx or _lib.default_context()
+    s, t, sn, tn = _c(source), _c(target), _c(source_normals), _c(target_normals)
+    T0 = None if init is None else np.ascontiguousarray(init, dtype=np.float64).reshape(4, 4)
+    T = np.empty((4, 4))
+    prm = _lib.IcpParams(int(mode), int(max_iteration), float(max_correspondence_distance), float(relative_fitness),
+                         float(relative_rmse), float(gicp_epsilon))
+    st = _lib.IcpStats()
+    ctx.call("r3d_icp", ctypes.byref(prm), _ptr(s), len(s), _ptr(sn), _ptr(t), len(t), _ptr(tn), _ptr(T0), _ptr(T),
+             ctypes.byref(st))
+    return dict(T=T, fitness=st.fitness, inlier_rmse=st.inlier_rmse, iterations=st.iterations,
+                converged=bool(st.converged), correspondences=st.correspondences)

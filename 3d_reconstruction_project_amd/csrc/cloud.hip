@@ -1,0 +1,951 @@
+// cloud.hip -- point-cloud half of the hot path for gfx950: uniform-grid neighbour search, voxel down-sampling,
+// hybrid / kNN PCA normals and the fused nearest-neighbour + Gauss-Newton reduction of ICP / point-to-plane / GICP.
+//
+// Replaces the Open3D (legacy, float64) calls the reference makes; semantics are those pinned in
+// oracle/cloud_oracle.py (fixture-verified for voxel / normals / SOR, [recalled] Open3D for registration):
+//   voxel_down_sample          pointcloud_alignment.py:22-23
+//   estimate_normals(Hybrid)   pointcloud_alignment.py:27-28, test/GICP1.py:77, normal_estimation.py:20
+//   registration_icp           pointcloud_alignment.py:35-39
+//   registration_generalized_icp   test/GICP1.py:99-102     point-to-plane: test/check2.py:151-154
+//   source.transform(T)        pointcloud_alignment.py:42
+// All geometry is float64 like the legacy Open3D classes (MI355X runs fp64 vector math at half the fp32 rate,
+// and these kernels are latency / LDS bound, not flop bound), which keeps voxel membership and neighbour sets
+// identical to the oracle's instead of "within tolerance".
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "r3d_internal.h"
+
+namespace {
+
+struct GridView {
+    double ox, oy, oz, cell, inv_cell;
+    int nx, ny, nz;
+    const int *cstart;     // [ncells] first sorted slot of the cell
+    const int *cend;       // [ncells] one past the last
+    const double *pts;     // [n][3] points in cell-sorted order
+    const int *idx;        // [n] sorted slot -> original index
+};
+
+__device__ __forceinline__ int cell_coord(double v, double o, double inv) { return (int)floor((v - o) * inv); }
+
+// ------------------------------------------------------------------------------------------------ bbox
+__global__ void __launch_bounds__(256) k_bbox_partial(const double *__restrict__ p, int64_t n, double *__restrict__ part) {
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        for (int a = 0; a < 3; a++) { double v = p[i * 3 + a]; mn[a] = fmin(mn[a], v); mx[a] = fmax(mx[a], v); }
+    __shared__ double sm[6][256];
+    for (int a = 0; a < 3; a++) { sm[a][threadIdx.x] = mn[a]; sm[3 + a][threadIdx.x] = mx[a]; }
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int a = 0; a < 3; a++) {
+                sm[a][threadIdx.x] = fmin(sm[a][threadIdx.x], sm[a][threadIdx.x + s]);
+                sm[3 + a][threadIdx.x] = fmax(sm[3 + a][threadIdx.x], sm[3 + a][threadIdx.x + s]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = sm[threadIdx.x][0];
+}
+
+// ------------------------------------------------------------------------------------------------ keys
+__global__ void __launch_bounds__(256) k_cell_keys(const double *__restrict__ p, int64_t n, double ox, double oy, double oz,
+                                                   double cell, int nx, int ny, int nz, int key_order,
+                                                   unsigned long long *__restrict__ keys, int *__restrict__ vals) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int cx, cy, cz;
+    if (key_order == 1) {  // voxel keys: the legacy index is floor((p - origin) / voxel) with a true division
+        cx = (int)floor((p[i * 3] - ox) / cell); cy = (int)floor((p[i * 3 + 1] - oy) / cell); cz = (int)floor((p[i * 3 + 2] - oz) / cell);
+    } else {               // search grid: must agree with cell_coord() used by the queries
+        const double inv = 1.0 / cell;
+        cx = cell_coord(p[i * 3], ox, inv); cy = cell_coord(p[i * 3 + 1], oy, inv); cz = cell_coord(p[i * 3 + 2], oz, inv);
+    }
+    cx = min(max(cx, 0), nx - 1); cy = min(max(cy, 0), ny - 1); cz = min(max(cz, 0), nz - 1);
+    // key_order 0: x fastest (search grid); 1: z fastest (voxel output in lexicographic (kx,ky,kz) order)
+    unsigned long long k = key_order == 0 ? ((unsigned long long)cz * ny + cy) * nx + cx : ((unsigned long long)cx * ny + cy) * nz + cz;
+    keys[i] = k;
+    vals[i] = (int)i;
+}
+
+__global__ void __launch_bounds__(256) k_cell_bounds(const unsigned long long *__restrict__ keys, int64_t n, int *__restrict__ cstart,
+                                                     int *__restrict__ cend) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long k = keys[i];
+    if (i == 0 || keys[i - 1] != k) cstart[k] = (int)i;
+    if (i == n - 1 || keys[i + 1] != k) cend[k] = (int)i + 1;
+}
+
+__global__ void __launch_bounds__(256) k_gather3(const double *__restrict__ src, const int *__restrict__ idx, int64_t n, double *__restrict__ dst) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int j = idx[i];
+    dst[i * 3] = src[(int64_t)j * 3]; dst[i * 3 + 1] = src[(int64_t)j * 3 + 1]; dst[i * 3 + 2] = src[(int64_t)j * 3 + 2];
+}
+
+// ------------------------------------------------------------------------------------------------ voxel
+// segment heads of the sorted key array -> compact list of segment starts (one output voxel per segment)
+__global__ void __launch_bounds__(256) k_seg_flags(const unsigned long long *__restrict__ keys, int64_t n, int *__restrict__ flags) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    flags[i] = (i == 0 || keys[i - 1] != keys[i]) ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_seg_starts(const int *__restrict__ flags, const int *__restrict__ scan, int64_t n, int *__restrict__ starts) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (flags[i]) starts[scan[i]] = (int)i;
+}
+// one thread per voxel: sequential float64 sums in ORIGINAL point order (stable sort), exactly like the
+// accumulate-then-divide of the legacy VoxelDownSample
+__global__ void __launch_bounds__(256) k_voxel_mean(const double *__restrict__ a, const int *__restrict__ idx, const int *__restrict__ starts,
+                                                    int64_t nseg, int64_t n, double *__restrict__ out) {
+    int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= nseg) return;
+    int b = starts[s], e = s + 1 < nseg ? starts[s + 1] : (int)n;
+    double x = 0, y = 0, z = 0;
+    for (int i = b; i < e; i++) { int64_t j = idx[i]; x += a[j * 3]; y += a[j * 3 + 1]; z += a[j * 3 + 2]; }
+    double c = (double)(e - b);
+    out[s * 3] = x / c; out[s * 3 + 1] = y / c; out[s * 3 + 2] = z / c;
+}
+
+// ------------------------------------------------------------------------------------------------ search
+// visits the cells of Chebyshev shell s around (cx,cy,cz); F(slot_begin, slot_end) is called per non-empty cell
+template <class F>
+__device__ __forceinline__ void for_shell(const GridView &g, int cx, int cy, int cz, int s, F &&f) {
+    for (int dz = -s; dz <= s; dz++) {
+        int z = cz + dz;
+        if (z < 0 || z >= g.nz) continue;
+        for (int dy = -s; dy <= s; dy++) {
+            int y = cy + dy;
+            if (y < 0 || y >= g.ny) continue;
+            const bool face = (dz == -s || dz == s || dy == -s || dy == s);
+            const int step = face ? 1 : 2 * s;  // interior rows of the shell only touch dx = -s and dx = +s
+            for (int dx = -s; dx <= s; dx += (step > 0 ? step : 1)) {
+                int x = cx + dx;
+                if (x < 0 || x >= g.nx) continue;
+                int64_t c = ((int64_t)z * g.ny + y) * g.nx + x;
+                int b = g.cstart[c], e = g.cend[c];
+                if (e > b) f(b, e);
+            }
+        }
+    }
+}
+
+// max shells needed to cover the whole grid from a clamped centre
+__device__ __forceinline__ int max_shell(const GridView &g, int cx, int cy, int cz) {
+    int m = max(max(cx, g.nx - 1 - cx), max(max(cy, g.ny - 1 - cy), max(cz, g.nz - 1 - cz)));
+    return max(m, 0);
+}
+
+// ---- k nearest (<= k, distance < radius if radius > 0), sorted ascending, in LDS columns [slot][thread]
+constexpr int KNN_BLOCK = 64;
+template <bool unused = true>
+__device__ __forceinline__ int knn_query(const GridView &g, double qx, double qy, double qz, int k, double radius,
+                                         double *sd /*[k][KNN_BLOCK] column tid*/, int *si) {
+    const int t = threadIdx.x;
+    const double r2 = radius > 0 ? radius * radius : 1e300;
+    int cnt = 0;
+    const int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
+    const int smax = max_shell(g, min(max(cx, 0), g.nx - 1), min(max(cy, 0), g.ny - 1), min(max(cz, 0), g.nz - 1)) + 1;
+    for (int s = 0; s <= smax; s++) {
+        for_shell(g, cx, cy, cz, s, [&](int b, int e) {
+            for (int i = b; i < e; i++) {
+                double dx = g.pts[(int64_t)i * 3] - qx, dy = g.pts[(int64_t)i * 3 + 1] - qy, dz = g.pts[(int64_t)i * 3 + 2] - qz;
+                double d2 = dx * dx + dy * dy + dz * dz;
+                if (!(d2 < r2)) continue;
+                if (cnt == k && !(d2 < sd[(k - 1) * KNN_BLOCK + t])) continue;
+                int pos = cnt < k ? cnt : k - 1;
+                while (pos > 0 && sd[(pos - 1) * KNN_BLOCK + t] > d2) {
+                    sd[pos * KNN_BLOCK + t] = sd[(pos - 1) * KNN_BLOCK + t];
+                    si[pos * KNN_BLOCK + t] = si[(pos - 1) * KNN_BLOCK + t];
+                    pos--;
+                }
+                sd[pos * KNN_BLOCK + t] = d2;
+                si[pos * KNN_BLOCK + t] = i;
+                if (cnt < k) cnt++;
+            }
+        });
+        // everything not visited yet is at least s*cell away
+        const double reach = s * g.cell;
+        if (radius > 0 && reach >= radius) break;
+        if (cnt == k && sd[(k - 1) * KNN_BLOCK + t] <= reach * reach) break;
+    }
+    return cnt;
+}
+
+// symmetric 3x3 eigen-decomposition (cyclic Jacobi, float64); returns the eigenvector of the smallest eigenvalue
+__device__ __forceinline__ void smallest_eigvec(double a00, double a01, double a02, double a11, double a12, double a22, double n[3]) {
+    double A[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 12; sweep++) {
+        double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (off < 1e-300) break;
+#pragma unroll
+        for (int pq = 0; pq < 3; pq++) {
+            const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+            if (fabs(A[p][q]) < 1e-300) continue;
+            double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+            double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {  // A <- A J
+                double akp = A[k][p], akq = A[k][q];
+                A[k][p] = c * akp - s * akq;
+                A[k][q] = s * akp + c * akq;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {  // A <- J^T A
+                double apk = A[p][k], aqk = A[q][k];
+                A[p][k] = c * apk - s * aqk;
+                A[q][k] = s * apk + c * aqk;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                double vkp = V[k][p], vkq = V[k][q];
+                V[k][p] = c * vkp - s * vkq;
+                V[k][q] = s * vkp + c * vkq;
+            }
+        }
+    }
+    // static selects only (a runtime column index would push V to scratch memory)
+    const bool m1 = A[1][1] < A[0][0];
+    const double e01 = m1 ? A[1][1] : A[0][0];
+    const bool m2 = A[2][2] < e01;
+    double x = m2 ? V[0][2] : (m1 ? V[0][1] : V[0][0]);
+    double y = m2 ? V[1][2] : (m1 ? V[1][1] : V[1][0]);
+    double z = m2 ? V[2][2] : (m1 ? V[2][1] : V[2][0]);
+    double l = sqrt(x * x + y * y + z * z);
+    n[0] = x / l; n[1] = y / l; n[2] = z / l;
+}
+
+// k_normals: one thread per (cell-sorted) point: hybrid / kNN search, population covariance, smallest eigenvector.
+// < 3 neighbours -> (0,0,1).  If prev != NULL the sign follows the previous normal (legacy EstimateNormals).
+__global__ void __launch_bounds__(KNN_BLOCK) k_normals(GridView g, int64_t n, int k, double radius, const double *__restrict__ prev,
+                                                       double *__restrict__ normals, int *__restrict__ nn_count) {
+    extern __shared__ double lds_d[];
+    double *sd = lds_d;
+    int *si = (int *)(lds_d + (size_t)k * KNN_BLOCK);
+    int64_t i = (int64_t)blockIdx.x * KNN_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int t = threadIdx.x;
+    const double qx = g.pts[i * 3], qy = g.pts[i * 3 + 1], qz = g.pts[i * 3 + 2];
+    const int cnt = knn_query(g, qx, qy, qz, k, radius, sd, si);
+    double nrm[3] = {0.0, 0.0, 1.0};
+    if (cnt >= 3) {
+        double sx = 0, sy = 0, sz = 0, xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+        for (int j = 0; j < cnt; j++) {
+            const int64_t s = si[j * KNN_BLOCK + t];
+            const double x = g.pts[s * 3] - qx, y = g.pts[s * 3 + 1] - qy, z = g.pts[s * 3 + 2] - qz;  // centred on the query
+            sx += x; sy += y; sz += z;
+            xx += x * x; xy += x * y; xz += x * z; yy += y * y; yz += y * z; zz += z * z;
+        }
+        const double inv = 1.0 / cnt;
+        sx *= inv; sy *= inv; sz *= inv;
+        smallest_eigvec(xx * inv - sx * sx, xy * inv - sx * sy, xz * inv - sx * sz, yy * inv - sy * sy, yz * inv - sy * sz,
+                        zz * inv - sz * sz, nrm);
+    }
+    const int64_t o = g.idx[i];
+    if (prev) {
+        if (nrm[0] * prev[o * 3] + nrm[1] * prev[o * 3 + 1] + nrm[2] * prev[o * 3 + 2] < 0) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
+    }
+    normals[o * 3] = nrm[0]; normals[o * 3 + 1] = nrm[1]; normals[o * 3 + 2] = nrm[2];
+    if (nn_count) nn_count[o] = cnt;
+}
+
+// k_knn_dist: mean of the k smallest distances (self included) -- statistical outlier removal's per-point score;
+// with count_radius > 0 instead counts the neighbours within that radius (radius outlier removal)
+__global__ void __launch_bounds__(KNN_BLOCK) k_knn_score(GridView g, int64_t n, int k, double count_radius, double *__restrict__ score) {
+    extern __shared__ double lds_d[];
+    double *sd = lds_d;
+    int *si = (int *)(lds_d + (size_t)k * KNN_BLOCK);
+    int64_t i = (int64_t)blockIdx.x * KNN_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int t = threadIdx.x;
+    const double qx = g.pts[i * 3], qy = g.pts[i * 3 + 1], qz = g.pts[i * 3 + 2];
+    if (count_radius > 0) {
+        const double r2 = count_radius * count_radius;
+        const int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
+        int c = 0;
+        const int smax = (int)ceil(count_radius * g.inv_cell);
+        for (int s = 0; s <= smax; s++)
+            for_shell(g, cx, cy, cz, s, [&](int b, int e) {
+                for (int j = b; j < e; j++) {
+                    double dx = g.pts[(int64_t)j * 3] - qx, dy = g.pts[(int64_t)j * 3 + 1] - qy, dz = g.pts[(int64_t)j * 3 + 2] - qz;
+                    if (dx * dx + dy * dy + dz * dz <= r2) c++;
+                }
+            });
+        score[g.idx[i]] = (double)c;
+        return;
+    }
+    const int cnt = knn_query(g, qx, qy, qz, k, -1.0, sd, si);
+    double a = 0;
+    for (int j = 0; j < cnt; j++) a += sqrt(sd[j * KNN_BLOCK + t]);
+    score[g.idx[i]] = cnt ? a / cnt : 0.0;
+}
+
+// k_knn_graph: indices (original numbering) and squared distances of the k nearest points, nearest first
+// (the point itself comes first); rows shorter than k are padded with -1 / +inf
+__global__ void __launch_bounds__(KNN_BLOCK) k_knn_graph(GridView g, int64_t n, int k, double radius, int *__restrict__ nbr,
+                                                         double *__restrict__ d2) {
+    extern __shared__ double lds_d[];
+    double *sd = lds_d;
+    int *si = (int *)(lds_d + (size_t)k * KNN_BLOCK);
+    int64_t i = (int64_t)blockIdx.x * KNN_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int t = threadIdx.x;
+    const int cnt = knn_query(g, g.pts[i * 3], g.pts[i * 3 + 1], g.pts[i * 3 + 2], k, radius, sd, si);
+    const int64_t o = g.idx[i];
+    for (int j = 0; j < k; j++) {
+        nbr[o * k + j] = j < cnt ? g.idx[si[j * KNN_BLOCK + t]] : -1;
+        if (d2) d2[o * k + j] = j < cnt ? sd[j * KNN_BLOCK + t] : 1e300;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ ICP
+// One launch = one "GetRegistrationResultAndCorrespondences" + the sums the NEXT ComputeTransformation needs:
+// for every source point p = T s: nearest target point within max_dist (strict <), then
+//   slots [0] n  [1] sum d^2
+//   P2P    : [2..4] sum p, [5..7] sum t, [8..16] sum p t^T (row-major p_i t_j)
+//   P2PLANE: [2..22] upper triangle of J^T J (J = [p x n_t ; n_t]), [23..28] J^T r, r = (p - t).n_t
+//   GICP   : same slots with J^T J = Jb^T M^-1 Jb, J^T r = Jb^T M^-1 d, Jb = [-[p]x | I], d = p - t,
+//            M = C_t + R C_s R^T with C = I - (1-eps) n n^T   (== W^T W with W = M^-1/2 of the original)
+constexpr int ICP_SLOTS = 29;
+constexpr int ICP_BLOCK = 256;
+enum { MODE_P2P = 0, MODE_P2PLANE = 1, MODE_GICP = 2 };
+
+struct Rigid { double r[9], t[3]; };
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ bool inv3_sym(const double m[6] /*xx xy xz yy yz zz*/, double a[6]) {
+    const double c00 = m[3] * m[5] - m[4] * m[4], c01 = m[2] * m[4] - m[1] * m[5], c02 = m[1] * m[4] - m[2] * m[3];
+    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    if (fabs(det) < 1e-300) return false;
+    const double id = 1.0 / det;
+    a[0] = c00 * id; a[1] = c01 * id; a[2] = c02 * id;
+    a[3] = (m[0] * m[5] - m[2] * m[2]) * id; a[4] = (m[1] * m[2] - m[0] * m[4]) * id; a[5] = (m[0] * m[3] - m[1] * m[1]) * id;
+    return true;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(ICP_BLOCK) k_icp_eval(GridView g, const double *__restrict__ src, const double *__restrict__ src_n,
+                                                        const double *__restrict__ tgt_n /* cell-sorted order */, int64_t ns, Rigid T,
+                                                        double max_dist, double eps, double *__restrict__ partial,
+                                                        int *__restrict__ corr /* optional [ns] target original index or -1 */) {
+    double acc[ICP_SLOTS];
+#pragma unroll
+    for (int q = 0; q < ICP_SLOTS; q++) acc[q] = 0;
+    const double r2 = max_dist * max_dist;
+    for (int64_t i = (int64_t)blockIdx.x * ICP_BLOCK + threadIdx.x; i < ns; i += (int64_t)gridDim.x * ICP_BLOCK) {
+        const double sx = src[i * 3], sy = src[i * 3 + 1], sz = src[i * 3 + 2];
+        const double px = T.r[0] * sx + T.r[1] * sy + T.r[2] * sz + T.t[0];
+        const double py = T.r[3] * sx + T.r[4] * sy + T.r[5] * sz + T.t[1];
+        const double pz = T.r[6] * sx + T.r[7] * sy + T.r[8] * sz + T.t[2];
+        const int cx = cell_coord(px, g.ox, g.inv_cell), cy = cell_coord(py, g.oy, g.inv_cell), cz = cell_coord(pz, g.oz, g.inv_cell);
+        double best = r2;
+        int bi = -1;
+        const int smax = (int)ceil(max_dist * g.inv_cell);
+        for (int s = 0; s <= smax; s++) {
+            for_shell(g, cx, cy, cz, s, [&](int b, int e) {
+                for (int j = b; j < e; j++) {
+                    double dx = g.pts[(int64_t)j * 3] - px, dy = g.pts[(int64_t)j * 3 + 1] - py, dz = g.pts[(int64_t)j * 3 + 2] - pz;
+                    double d2 = dx * dx + dy * dy + dz * dz;
+                    if (d2 < best) { best = d2; bi = j; }
+                }
+            });
+            const double reach = s * g.cell;
+            if (bi >= 0 && best <= reach * reach) break;
+        }
+        if (corr) corr[i] = bi >= 0 ? g.idx[bi] : -1;
+        if (bi < 0) continue;
+        const double tx = g.pts[(int64_t)bi * 3], ty = g.pts[(int64_t)bi * 3 + 1], tz = g.pts[(int64_t)bi * 3 + 2];
+        acc[0] += 1.0;
+        acc[1] += best;
+        if (MODE == MODE_P2P) {
+            acc[2] += px; acc[3] += py; acc[4] += pz;
+            acc[5] += tx; acc[6] += ty; acc[7] += tz;
+            acc[8] += px * tx; acc[9] += px * ty; acc[10] += px * tz;
+            acc[11] += py * tx; acc[12] += py * ty; acc[13] += py * tz;
+            acc[14] += pz * tx; acc[15] += pz * ty; acc[16] += pz * tz;
+        } else {
+            double J[3][6], rr[3];
+            int rows;
+            const double nx = tgt_n[(int64_t)bi * 3], ny = tgt_n[(int64_t)bi * 3 + 1], nz = tgt_n[(int64_t)bi * 3 + 2];
+            const double dx = px - tx, dy = py - ty, dz = pz - tz;
+            if (MODE == MODE_P2PLANE) {
+                rows = 1;
+                J[0][0] = py * nz - pz * ny; J[0][1] = pz * nx - px * nz; J[0][2] = px * ny - py * nx;
+                J[0][3] = nx; J[0][4] = ny; J[0][5] = nz;
+                rr[0] = dx * nx + dy * ny + dz * nz;
+#pragma unroll
+                for (int a = 0, q = 2; a < 6; a++)
+#pragma unroll
+                    for (int b = a; b < 6; b++, q++) acc[q] += J[0][a] * J[0][b];
+#pragma unroll
+                for (int a = 0; a < 6; a++) acc[23 + a] += J[0][a] * rr[0];
+            } else {
+                rows = 3;
+                (void)rows;
+                // effective normals (QUIRK of GetRotationFromE1ToX: n.e1 < -0.99 -> e1)
+                double ax = nx, ay = ny, az = nz;
+                if (ax < -0.99) { ax = 1; ay = 0; az = 0; }
+                double ux = src_n[i * 3], uy = src_n[i * 3 + 1], uz = src_n[i * 3 + 2];
+                if (ux < -0.99) { ux = 1; uy = 0; uz = 0; }
+                const double bx = T.r[0] * ux + T.r[1] * uy + T.r[2] * uz, by = T.r[3] * ux + T.r[4] * uy + T.r[5] * uz,
+                             bz = T.r[6] * ux + T.r[7] * uy + T.r[8] * uz;
+                const double w = 1.0 - eps;
+                double M[6] = {2.0 - w * (ax * ax + bx * bx), -w * (ax * ay + bx * by), -w * (ax * az + bx * bz),
+                               2.0 - w * (ay * ay + by * by), -w * (ay * az + by * bz), 2.0 - w * (az * az + bz * bz)};
+                double A[6];
+                if (!inv3_sym(M, A)) continue;
+                // Jb = [K | I], K = -[p]x ; G = A * Jb (3x6) ; JtJ = Jb^T G ; Jtr = Jb^T (A d)
+                const double K[3][3] = {{0, pz, -py}, {-pz, 0, px}, {py, -px, 0}};
+                const double As[3][3] = {{A[0], A[1], A[2]}, {A[1], A[3], A[4]}, {A[2], A[4], A[5]}};
+                double G[3][6];
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+#pragma unroll
+                    for (int b = 0; b < 3; b++) {
+                        G[a][b] = As[a][0] * K[0][b] + As[a][1] * K[1][b] + As[a][2] * K[2][b];
+                        G[a][3 + b] = As[a][b];
+                    }
+                }
+                double Jb[3][6];
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) { Jb[a][b] = K[a][b]; Jb[a][3 + b] = a == b ? 1.0 : 0.0; }
+                const double Ad[3] = {As[0][0] * dx + As[0][1] * dy + As[0][2] * dz, As[1][0] * dx + As[1][1] * dy + As[1][2] * dz,
+                                      As[2][0] * dx + As[2][1] * dy + As[2][2] * dz};
+#pragma unroll
+                for (int a = 0, q = 2; a < 6; a++)
+#pragma unroll
+                    for (int b = a; b < 6; b++, q++) acc[q] += Jb[0][a] * G[0][b] + Jb[1][a] * G[1][b] + Jb[2][a] * G[2][b];
+#pragma unroll
+                for (int a = 0; a < 6; a++) acc[23 + a] += Jb[0][a] * Ad[0] + Jb[1][a] * Ad[1] + Jb[2][a] * Ad[2];
+            }
+        }
+    }
+    __shared__ double sm[ICP_BLOCK / 64][ICP_SLOTS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < ICP_SLOTS; q++) {
+        double v = wave_sum(acc[q]);
+        if (lane == 0) sm[wv][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < ICP_SLOTS) {
+        double v = 0;
+        for (int w2 = 0; w2 < ICP_BLOCK / 64; w2++) v += sm[w2][threadIdx.x];
+        partial[(size_t)blockIdx.x * ICP_SLOTS + threadIdx.x] = v;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_icp_final(const double *__restrict__ partial, int nblocks, double *__restrict__ out) {
+    if (threadIdx.x >= ICP_SLOTS) return;
+    double v = 0;
+    for (int b = 0; b < nblocks; b++) v += partial[(size_t)b * ICP_SLOTS + threadIdx.x];  // fixed order: deterministic
+    out[threadIdx.x] = v;
+}
+
+__global__ void __launch_bounds__(256) k_transform(const double *__restrict__ in, int64_t n, Rigid T, int rotate_only, double *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double x = in[i * 3], y = in[i * 3 + 1], z = in[i * 3 + 2];
+    const double tx = rotate_only ? 0 : T.t[0], ty = rotate_only ? 0 : T.t[1], tz = rotate_only ? 0 : T.t[2];
+    out[i * 3] = T.r[0] * x + T.r[1] * y + T.r[2] * z + tx;
+    out[i * 3 + 1] = T.r[3] * x + T.r[4] * y + T.r[5] * z + ty;
+    out[i * 3 + 2] = T.r[6] * x + T.r[7] * y + T.r[8] * z + tz;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct DevArena {  // simple bump allocator over ctx->cloud_bufs (grow-only, reused across calls)
+    r3d_ctx *ctx;
+    size_t next = 0;
+    int rc = R3D_OK;
+    explicit DevArena(r3d_ctx *c) : ctx(c) {}
+    void *get(size_t bytes) {
+        if (rc) return nullptr;
+        if (next >= ctx->cloud_bufs.size()) ctx->cloud_bufs.emplace_back();
+        r3d_buf &b = ctx->cloud_bufs[next++];
+        rc = r3d_reserve(ctx, b, bytes ? bytes : 16);
+        return rc ? nullptr : b.p;
+    }
+};
+
+struct Grid {
+    GridView v;
+    int64_t n = 0;
+    int64_t ncells = 0;
+    unsigned long long *keys = nullptr;  // sorted keys
+    double mn[3], mx[3];
+};
+
+int cloud_bbox(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, double mn[3], double mx[3]) {
+    const int nb = (int)std::min<int64_t>((n + 255) / 256, 1024);
+    double *part = (double *)ar.get((size_t)nb * 6 * 8);
+    if (ar.rc) return ar.rc;
+    k_bbox_partial<<<nb, 256, 0, ctx->stream>>>(d_pts, n, part);
+    R3D_HIP(ctx, hipGetLastError());
+    std::vector<double> h((size_t)nb * 6);
+    R3D_HIP(ctx, hipMemcpyAsync(h.data(), part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int a = 0; a < 3; a++) { mn[a] = 1e300; mx[a] = -1e300; }
+    for (int b = 0; b < nb; b++)
+        for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], h[(size_t)b * 6 + a]); mx[a] = std::max(mx[a], h[(size_t)b * 6 + 3 + a]); }
+    return R3D_OK;
+}
+
+// sorts point indices by cell key; fills keys_sorted / idx_sorted (device)
+int sort_by_cell(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, const double org[3], double cell, const int dims[3],
+                 int key_order, unsigned long long **keys_sorted, int **idx_sorted) {
+    unsigned long long *k0 = (unsigned long long *)ar.get((size_t)n * 8), *k1 = (unsigned long long *)ar.get((size_t)n * 8);
+    int *v0 = (int *)ar.get((size_t)n * 4), *v1 = (int *)ar.get((size_t)n * 4);
+    if (ar.rc) return ar.rc;
+    const int nb = (int)((n + 255) / 256);
+    k_cell_keys<<<nb, 256, 0, ctx->stream>>>(d_pts, n, org[0], org[1], org[2], cell, dims[0], dims[1], dims[2], key_order, k0, v0);
+    R3D_HIP(ctx, hipGetLastError());
+    const unsigned long long maxkey = (unsigned long long)dims[0] * dims[1] * dims[2];
+    int bits = 1;
+    while (bits < 64 && (maxkey >> bits)) bits++;
+    size_t tb = 0;
+    R3D_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k0, k1, v0, v1, (int)n, 0, bits, ctx->stream));
+    void *tmp = ar.get(tb);
+    if (ar.rc) return ar.rc;
+    R3D_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, tb, k0, k1, v0, v1, (int)n, 0, bits, ctx->stream));
+    *keys_sorted = k1;
+    *idx_sorted = v1;
+    return R3D_OK;
+}
+
+// Builds the search grid.  cell_hint: minimum useful cell (search radius, or <= 0 for pure kNN); the cell is
+// refined so that occupied cells hold about `target_occ` points, and coarsened to keep the dense table <= 2^26 cells.
+int grid_build(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, double cell_hint, double target_occ, Grid &G) {
+    if (n <= 0) return r3d_fail(ctx, R3D_E_BADARG, "grid: empty cloud");
+    if (n > 0x7fffffff) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "grid: more than 2^31-1 points");
+    int rc = cloud_bbox(ctx, ar, d_pts, n, G.mn, G.mx);
+    if (rc) return rc;
+    double ext[3];
+    for (int a = 0; a < 3; a++) ext[a] = std::max(G.mx[a] - G.mn[a], 1e-9);
+    // surface-like data: occupied cells ~ (extent/cell)^2 * const.  Start from the volume / area heuristic and clamp.
+    const double diag = std::sqrt(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2]);
+    double cell = cell_hint > 0 ? cell_hint : diag / std::max(1.0, std::sqrt((double)n / std::max(target_occ, 1.0)));
+    if (cell_hint > 0 && target_occ > 0) {
+        // estimate occupancy at cell_hint assuming a 2-manifold: area ~ n * spacing^2, spacing from bbox area
+        const double area = 2.0 * (ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2]) / 2.0;  // rough
+        const double per_cell = (double)n * cell_hint * cell_hint / std::max(area, 1e-30);
+        int m = (int)std::floor(std::sqrt(std::max(per_cell / target_occ, 1.0)));
+        m = std::max(1, std::min(m, 16));
+        cell = cell_hint / m;
+    }
+    int dims[3];
+    for (;;) {
+        double nc = 1;
+        for (int a = 0; a < 3; a++) { dims[a] = (int)std::floor(ext[a] / cell) + 1; nc *= dims[a]; }
+        if (nc <= (double)(1 << 26)) break;
+        cell *= 1.26;
+    }
+    G.n = n;
+    G.ncells = (int64_t)dims[0] * dims[1] * dims[2];
+    int *idx;
+    rc = sort_by_cell(ctx, ar, d_pts, n, G.mn, cell, dims, 0, &G.keys, &idx);
+    if (rc) return rc;
+    int *cs = (int *)ar.get((size_t)G.ncells * 4), *ce = (int *)ar.get((size_t)G.ncells * 4);
+    double *sorted = (double *)ar.get((size_t)n * 24);
+    if (ar.rc) return ar.rc;
+    R3D_HIP(ctx, hipMemsetAsync(cs, 0, (size_t)G.ncells * 4, ctx->stream));
+    R3D_HIP(ctx, hipMemsetAsync(ce, 0, (size_t)G.ncells * 4, ctx->stream));
+    const int nb = (int)((n + 255) / 256);
+    k_cell_bounds<<<nb, 256, 0, ctx->stream>>>(G.keys, n, cs, ce);
+    k_gather3<<<nb, 256, 0, ctx->stream>>>(d_pts, idx, n, sorted);
+    R3D_HIP(ctx, hipGetLastError());
+    G.v = GridView{G.mn[0], G.mn[1], G.mn[2], cell, 1.0 / cell, dims[0], dims[1], dims[2], cs, ce, sorted, idx};
+    return R3D_OK;
+}
+
+Rigid to_rigid(const double T[16]) {
+    Rigid r;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) r.r[i * 3 + j] = T[i * 4 + j];
+        r.t[i] = T[i * 4 + 3];
+    }
+    return r;
+}
+void mat4_mul(const double A[16], const double B[16], double C[16]) {
+    double t[16];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = 0;
+            for (int k = 0; k < 4; k++) s += A[i * 4 + k] * B[k * 4 + j];
+            t[i * 4 + j] = s;
+        }
+    memcpy(C, t, sizeof t);
+}
+
+// 3x3 SVD via Jacobi eigen-decomposition of S^T S (host, float64) -- only used for the 3x3 Kabsch/Umeyama step
+void jacobi_eig3(double A[3][3], double V[3][3]) {
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) V[i][j] = i == j;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                double theta = (A[q][q] - A[p][p]) / (2 * A[p][q]);
+                double t = (theta >= 0 ? 1 : -1) / (fabs(theta) + sqrt(theta * theta + 1));
+                double c = 1 / sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < 3; k++) { double a = A[k][p], b = A[k][q]; A[k][p] = c * a - s * b; A[k][q] = s * a + c * b; }
+                for (int k = 0; k < 3; k++) { double a = A[p][k], b = A[q][k]; A[p][k] = c * a - s * b; A[q][k] = s * a + c * b; }
+                for (int k = 0; k < 3; k++) { double a = V[k][p], b = V[k][q]; V[k][p] = c * a - s * b; V[k][q] = s * a + c * b; }
+            }
+    }
+}
+double det3(const double M[3][3]) {
+    return M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+           M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+}
+// Eigen::umeyama(src, dst, false) from the accumulated sums: returns U (4x4) mapping src -> dst
+void umeyama_from_sums(const double *s /*ICP slots*/, double U[16]) {
+    const double n = s[0];
+    const double ps[3] = {s[2] / n, s[3] / n, s[4] / n}, pt[3] = {s[5] / n, s[6] / n, s[7] / n};
+    double sigma[3][3];  // (1/n) sum (t - mt)(p - mp)^T  = E[t p^T] - mt mp^T ; slots hold p_i t_j
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) sigma[i][j] = s[8 + j * 3 + i] / n - pt[i] * ps[j];
+    // SVD sigma = Us D Vs^T through the symmetric eigenproblems
+    double StS[3][3], V[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { StS[i][j] = 0; for (int k = 0; k < 3; k++) StS[i][j] += sigma[k][i] * sigma[k][j]; }
+    jacobi_eig3(StS, V);
+    int ord[3] = {0, 1, 2};
+    std::sort(ord, ord + 3, [&](int a, int b) { return StS[a][a] > StS[b][b]; });
+    double Vs[3][3], Us[3][3], sv[3];
+    for (int c = 0; c < 3; c++) {
+        for (int r = 0; r < 3; r++) Vs[r][c] = V[r][ord[c]];
+        sv[c] = sqrt(std::max(StS[ord[c]][ord[c]], 0.0));
+    }
+    for (int c = 0; c < 3; c++) {
+        double u[3] = {0, 0, 0};
+        for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) u[r] += sigma[r][k] * Vs[k][c];
+        double l = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        if (l > 1e-300 && sv[c] > 1e-14 * std::max(sv[0], 1e-300)) for (int r = 0; r < 3; r++) Us[r][c] = u[r] / l;
+        else {  // rank-deficient: complete the basis
+            const int a = (c + 1) % 3, b = (c + 2) % 3;
+            Us[0][c] = Us[1][a] * Us[2][b] - Us[2][a] * Us[1][b];
+            Us[1][c] = Us[2][a] * Us[0][b] - Us[0][a] * Us[2][b];
+            Us[2][c] = Us[0][a] * Us[1][b] - Us[1][a] * Us[0][b];
+        }
+    }
+    double S[3] = {1, 1, 1};
+    if (det3(Us) * det3(Vs) < 0) S[2] = -1;
+    double R[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { R[i][j] = 0; for (int k = 0; k < 3; k++) R[i][j] += Us[i][k] * S[k] * Vs[j][k]; }
+    for (int i = 0; i < 16; i++) U[i] = (i % 5 == 0);
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) U[i * 4 + j] = R[i][j];
+        U[i * 4 + 3] = pt[i] - (R[i][0] * ps[0] + R[i][1] * ps[1] + R[i][2] * ps[2]);
+    }
+}
+
+// SolveJacobianSystemAndObtainExtrinsicMatrix: x = LDLT(JTJ) \ (-JTr); identity when |det| < 1e-6
+bool solve6_to_matrix(const double *s, double U[16]) {
+    double A[6][6], b[6];
+    for (int a = 0, q = 2; a < 6; a++)
+        for (int c = a; c < 6; c++, q++) A[a][c] = A[c][a] = s[q];
+    for (int a = 0; a < 6; a++) b[a] = -s[23 + a];
+    // LDL^T
+    double L[6][6] = {}, Dg[6];
+    double det = 1;
+    for (int j = 0; j < 6; j++) {
+        double d = A[j][j];
+        for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k] * Dg[k];
+        Dg[j] = d;
+        det *= d;
+        L[j][j] = 1;
+        for (int i = j + 1; i < 6; i++) {
+            double v = A[i][j];
+            for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k] * Dg[k];
+            L[i][j] = d != 0 ? v / d : 0;
+        }
+    }
+    for (int i = 0; i < 16; i++) U[i] = (i % 5 == 0);
+    if (!std::isfinite(det) || fabs(det) < 1e-6) return false;
+    double y[6], x[6];
+    for (int i = 0; i < 6; i++) { y[i] = b[i]; for (int k = 0; k < i; k++) y[i] -= L[i][k] * y[k]; }
+    for (int i = 0; i < 6; i++) y[i] /= Dg[i];
+    for (int i = 5; i >= 0; i--) { x[i] = y[i]; for (int k = i + 1; k < 6; k++) x[i] -= L[k][i] * x[k]; }
+    // TransformVector6dToMatrix4d: R = Rz(x2) Ry(x1) Rx(x0)
+    const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cc = cos(x[2]), sc = sin(x[2]);
+    const double R[9] = {cc * cb, cc * sb * sa - sc * ca, cc * sb * ca + sc * sa, sc * cb, sc * sb * sa + cc * ca, sc * sb * ca - cc * sa,
+                         -sb, cb * sa, cb * ca};
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) U[i * 4 + j] = R[i * 3 + j];
+        U[i * 4 + 3] = x[3 + i];
+    }
+    return true;
+}
+
+int upload(r3d_ctx *ctx, DevArena &ar, const double *h, int64_t n3, double **d) {
+    *d = (double *)ar.get((size_t)n3 * 8);
+    if (ar.rc) return ar.rc;
+    R3D_HIP(ctx, hipMemcpyAsync(*d, h, (size_t)n3 * 8, hipMemcpyHostToDevice, ctx->stream));
+    return R3D_OK;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+int r3d_voxel_downsample(r3d_ctx *ctx, const double *xyz, const double *colors, const double *normals, int64_t n, double voxel,
+                         double *out_xyz, double *out_colors, double *out_normals, int64_t *out_n) {
+    if (!ctx) return R3D_E_BADARG;
+    if (!xyz || !out_xyz || !out_n || n <= 0 || !(voxel > 0)) return r3d_fail(ctx, R3D_E_BADARG, "voxel_downsample: bad argument");
+    if ((colors && !out_colors) || (normals && !out_normals)) return r3d_fail(ctx, R3D_E_BADARG, "voxel_downsample: missing output array");
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    DevArena ar(ctx);
+    double *d_p, *d_c = nullptr, *d_n = nullptr;
+    int rc;
+    if ((rc = upload(ctx, ar, xyz, n * 3, &d_p))) return rc;
+    if (colors && (rc = upload(ctx, ar, colors, n * 3, &d_c))) return rc;
+    if (normals && (rc = upload(ctx, ar, normals, n * 3, &d_n))) return rc;
+    double mn[3], mx[3];
+    if ((rc = cloud_bbox(ctx, ar, d_p, n, mn, mx))) return rc;
+    double org[3];
+    int dims[3];
+    double total = 1;
+    for (int a = 0; a < 3; a++) {
+        org[a] = mn[a] - 0.5 * voxel;  // legacy: voxel_min_bound = min_bound - voxel_size * 0.5
+        dims[a] = (int)std::floor((mx[a] - org[a]) / voxel) + 2;
+        total *= dims[a];
+    }
+    if (total >= 1.8e19) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "voxel_downsample: voxel grid exceeds 2^64 cells");
+    unsigned long long *keys;
+    int *idx;
+    // key_order 1: exact legacy index floor((p - origin) / voxel), z fastest => output in lexicographic (kx,ky,kz) order
+    if ((rc = sort_by_cell(ctx, ar, d_p, n, org, voxel, dims, 1, &keys, &idx))) return rc;
+    int *flags = (int *)ar.get((size_t)n * 4), *scan = (int *)ar.get((size_t)n * 4), *starts = (int *)ar.get((size_t)n * 4);
+    if (ar.rc) return ar.rc;
+    const int nb = (int)((n + 255) / 256);
+    k_seg_flags<<<nb, 256, 0, ctx->stream>>>(keys, n, flags);
+    size_t tb = 0;
+    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flags, scan, (int)n, ctx->stream));
+    void *tmp = ar.get(tb);
+    if (ar.rc) return ar.rc;
+    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tb, flags, scan, (int)n, ctx->stream));
+    k_seg_starts<<<nb, 256, 0, ctx->stream>>>(flags, scan, n, starts);
+    int last_scan = 0, last_flag = 0;
+    R3D_HIP(ctx, hipMemcpyAsync(&last_scan, scan + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipMemcpyAsync(&last_flag, flags + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t nseg = (int64_t)last_scan + last_flag;
+    double *d_out = (double *)ar.get((size_t)nseg * 24);
+    if (ar.rc) return ar.rc;
+    const int nbs = (int)((nseg + 255) / 256);
+    const double *ins[3] = {d_p, d_c, d_n};
+    double *outs[3] = {out_xyz, out_colors, out_normals};
+    for (int a = 0; a < 3; a++) {
+        if (!ins[a]) continue;
+        k_voxel_mean<<<nbs, 256, 0, ctx->stream>>>(ins[a], idx, starts, nseg, n, d_out);
+        R3D_HIP(ctx, hipGetLastError());
+        R3D_HIP(ctx, hipMemcpyAsync(outs[a], d_out, (size_t)nseg * 24, hipMemcpyDeviceToHost, ctx->stream));
+        R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *out_n = nseg;
+    return R3D_OK;
+}
+
+int r3d_estimate_normals(r3d_ctx *ctx, const double *xyz, int64_t n, double radius, int32_t max_nn, const double *prev_normals,
+                         double *normals) {
+    if (!ctx) return R3D_E_BADARG;
+    if (!xyz || !normals || n <= 0 || max_nn < 1) return r3d_fail(ctx, R3D_E_BADARG, "estimate_normals: bad argument");
+    if (max_nn > 128) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "estimate_normals: max_nn > 128 not supported");
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    DevArena ar(ctx);
+    double *d_p, *d_prev = nullptr;
+    int rc;
+    if ((rc = upload(ctx, ar, xyz, n * 3, &d_p))) return rc;
+    if (prev_normals && (rc = upload(ctx, ar, prev_normals, n * 3, &d_prev))) return rc;
+    Grid G;
+    const int k = (int)std::min<int64_t>(max_nn, n);
+    if ((rc = grid_build(ctx, ar, d_p, n, radius, std::max(2.0, k / 5.0), G))) return rc;
+    double *d_n = (double *)ar.get((size_t)n * 24);
+    if (ar.rc) return ar.rc;
+    const size_t lds = (size_t)k * KNN_BLOCK * 12;
+    R3D_HIP(ctx, hipFuncSetAttribute((const void *)k_normals, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_normals<<<(unsigned)((n + KNN_BLOCK - 1) / KNN_BLOCK), KNN_BLOCK, lds, ctx->stream>>>(G.v, n, k, radius, d_prev, d_n, nullptr);
+    R3D_HIP(ctx, hipGetLastError());
+    R3D_HIP(ctx, hipMemcpyAsync(normals, d_n, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return R3D_OK;
+}
+
+int r3d_neighbor_score(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, double count_radius, double *score) {
+    if (!ctx) return R3D_E_BADARG;
+    if (!xyz || !score || n <= 0 || (count_radius <= 0 && k < 1)) return r3d_fail(ctx, R3D_E_BADARG, "neighbor_score: bad argument");
+    if (k > 128) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "neighbor_score: k > 128 not supported");
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    DevArena ar(ctx);
+    double *d_p;
+    int rc;
+    if ((rc = upload(ctx, ar, xyz, n * 3, &d_p))) return rc;
+    Grid G;
+    const int kk = (int)std::min<int64_t>(std::max(k, 1), n);
+    if ((rc = grid_build(ctx, ar, d_p, n, count_radius > 0 ? count_radius : -1.0, std::max(2.0, kk / 5.0), G))) return rc;
+    double *d_s = (double *)ar.get((size_t)n * 8);
+    if (ar.rc) return ar.rc;
+    const size_t lds = (size_t)kk * KNN_BLOCK * 12;
+    R3D_HIP(ctx, hipFuncSetAttribute((const void *)k_knn_score, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_knn_score<<<(unsigned)((n + KNN_BLOCK - 1) / KNN_BLOCK), KNN_BLOCK, lds, ctx->stream>>>(G.v, n, kk, count_radius, d_s);
+    R3D_HIP(ctx, hipGetLastError());
+    R3D_HIP(ctx, hipMemcpyAsync(score, d_s, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return R3D_OK;
+}
+
+int r3d_knn_graph(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, double radius, int32_t *nbr, double *d2) {
+    if (!ctx) return R3D_E_BADARG;
+    if (!xyz || !nbr || n <= 0 || k < 1) return r3d_fail(ctx, R3D_E_BADARG, "knn_graph: bad argument");
+    if (k > 128) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "knn_graph: k > 128 not supported");
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    DevArena ar(ctx);
+    double *d_p;
+    int rc;
+    if ((rc = upload(ctx, ar, xyz, n * 3, &d_p))) return rc;
+    Grid G;
+    if ((rc = grid_build(ctx, ar, d_p, n, radius, std::max(2.0, k / 5.0), G))) return rc;
+    int *d_nb = (int *)ar.get((size_t)n * k * 4);
+    double *d_d2 = d2 ? (double *)ar.get((size_t)n * k * 8) : nullptr;
+    if (ar.rc) return ar.rc;
+    const size_t lds = (size_t)k * KNN_BLOCK * 12;
+    R3D_HIP(ctx, hipFuncSetAttribute((const void *)k_knn_graph, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_knn_graph<<<(unsigned)((n + KNN_BLOCK - 1) / KNN_BLOCK), KNN_BLOCK, lds, ctx->stream>>>(G.v, n, k, radius, d_nb, d_d2);
+    R3D_HIP(ctx, hipGetLastError());
+    R3D_HIP(ctx, hipMemcpyAsync(nbr, d_nb, (size_t)n * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (d2) R3D_HIP(ctx, hipMemcpyAsync(d2, d_d2, (size_t)n * k * 8, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return R3D_OK;
+}
+
+int r3d_transform_points(r3d_ctx *ctx, const double *xyz, int64_t n, const double *T4x4, int32_t rotate_only, double *out) {
+    if (!ctx) return R3D_E_BADARG;
+    if (!xyz || !out || !T4x4 || n <= 0) return r3d_fail(ctx, R3D_E_BADARG, "transform_points: bad argument");
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    DevArena ar(ctx);
+    double *d_p;
+    int rc;
+    if ((rc = upload(ctx, ar, xyz, n * 3, &d_p))) return rc;
+    double *d_o = (double *)ar.get((size_t)n * 24);
+    if (ar.rc) return ar.rc;
+    k_transform<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(d_p, n, to_rigid(T4x4), rotate_only, d_o);
+    R3D_HIP(ctx, hipGetLastError());
+    R3D_HIP(ctx, hipMemcpyAsync(out, d_o, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return R3D_OK;
+}
+
+int r3d_icp(r3d_ctx *ctx, const r3d_icp_params *p, const double *src, int64_t ns, const double *src_normals, const double *tgt,
+            int64_t nt, const double *tgt_normals, const double *init4x4, double *T4x4, r3d_icp_stats *stats) {
+    if (!ctx) return R3D_E_BADARG;
+    if (!p || !src || !tgt || !T4x4 || ns <= 0 || nt <= 0) return r3d_fail(ctx, R3D_E_BADARG, "icp: bad argument");
+    if (p->mode < 0 || p->mode > 2) return r3d_fail(ctx, R3D_E_BADARG, "icp: mode must be 0 (P2P), 1 (P2PLANE) or 2 (GICP)");
+    if (!(p->max_correspondence_distance > 0)) return r3d_fail(ctx, R3D_E_BADARG, "icp: max_correspondence_distance must be > 0");
+    if (p->mode != MODE_P2P && !tgt_normals) return r3d_fail(ctx, R3D_E_BADARG, "icp: target normals required for this mode");
+    if (p->mode == MODE_GICP && !src_normals) return r3d_fail(ctx, R3D_E_BADARG, "icp: source normals required for GICP");
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    DevArena ar(ctx);
+    int rc;
+    double *d_t, *d_tn = nullptr, *d_s, *d_sn = nullptr;
+    if ((rc = upload(ctx, ar, tgt, nt * 3, &d_t))) return rc;
+    if ((rc = upload(ctx, ar, src, ns * 3, &d_s))) return rc;
+    if (src_normals && (rc = upload(ctx, ar, src_normals, ns * 3, &d_sn))) return rc;
+    Grid G;
+    if ((rc = grid_build(ctx, ar, d_t, nt, p->max_correspondence_distance, 3.0, G))) return rc;
+    double *d_tns = nullptr;
+    if (tgt_normals) {
+        if ((rc = upload(ctx, ar, tgt_normals, nt * 3, &d_tn))) return rc;
+        d_tns = (double *)ar.get((size_t)nt * 24);
+        if (ar.rc) return ar.rc;
+        k_gather3<<<(unsigned)((nt + 255) / 256), 256, 0, ctx->stream>>>(d_tn, G.v.idx, nt, d_tns);
+    }
+    // spatially sort the source once (by target-grid cell of its initial pose) so that neighbouring threads walk the
+    // same cells; sums are order-dependent only at the 1e-16 level and stay deterministic
+    double T[16];
+    if (init4x4) memcpy(T, init4x4, sizeof T);
+    else for (int i = 0; i < 16; i++) T[i] = (i % 5 == 0);
+    {
+        double *d_s0 = (double *)ar.get((size_t)ns * 24);
+        if (ar.rc) return ar.rc;
+        k_transform<<<(unsigned)((ns + 255) / 256), 256, 0, ctx->stream>>>(d_s, ns, to_rigid(T), 0, d_s0);
+        int dims[3] = {G.v.nx, G.v.ny, G.v.nz};
+        unsigned long long *sk;
+        int *sidx;
+        if ((rc = sort_by_cell(ctx, ar, d_s0, ns, G.mn, G.v.cell, dims, 0, &sk, &sidx))) return rc;
+        double *d_ss = (double *)ar.get((size_t)ns * 24);
+        if (ar.rc) return ar.rc;
+        k_gather3<<<(unsigned)((ns + 255) / 256), 256, 0, ctx->stream>>>(d_s, sidx, ns, d_ss);
+        d_s = d_ss;
+        if (d_sn) {
+            double *d_sns = (double *)ar.get((size_t)ns * 24);
+            if (ar.rc) return ar.rc;
+            k_gather3<<<(unsigned)((ns + 255) / 256), 256, 0, ctx->stream>>>(d_sn, sidx, ns, d_sns);
+            d_sn = d_sns;
+        }
+    }
+    const int nblocks = (int)std::min<int64_t>((ns + ICP_BLOCK - 1) / ICP_BLOCK, 2048);
+    double *d_part = (double *)ar.get((size_t)nblocks * ICP_SLOTS * 8), *d_sum = (double *)ar.get(ICP_SLOTS * 8);
+    if (ar.rc) return ar.rc;
+    double sums[ICP_SLOTS];
+    auto eval = [&](const double Tm[16]) -> int {
+        Rigid R = to_rigid(Tm);
+        const double eps = p->gicp_epsilon > 0 ? p->gicp_epsilon : 1e-3;
+        switch (p->mode) {
+            case MODE_P2P: k_icp_eval<MODE_P2P><<<nblocks, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, p->max_correspondence_distance, eps, d_part, nullptr); break;
+            case MODE_P2PLANE: k_icp_eval<MODE_P2PLANE><<<nblocks, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, p->max_correspondence_distance, eps, d_part, nullptr); break;
+            default: k_icp_eval<MODE_GICP><<<nblocks, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, p->max_correspondence_distance, eps, d_part, nullptr); break;
+        }
+        k_icp_final<<<1, 64, 0, ctx->stream>>>(d_part, nblocks, d_sum);
+        R3D_HIP(ctx, hipGetLastError());
+        R3D_HIP(ctx, hipMemcpyAsync(sums, d_sum, sizeof sums, hipMemcpyDeviceToHost, ctx->stream));
+        R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return R3D_OK;
+    };
+    if ((rc = eval(T))) return rc;
+    double fit = sums[0] / (double)ns, rmse = sums[0] > 0 ? sqrt(sums[1] / sums[0]) : 0.0;
+    int it = 0, converged = 0;
+    const int max_it = p->max_iteration;
+    for (it = 1; it <= max_it; it++) {
+        double U[16];
+        for (int i = 0; i < 16; i++) U[i] = (i % 5 == 0);
+        if (sums[0] > 0) {
+            if (p->mode == MODE_P2P) umeyama_from_sums(sums, U);
+            else solve6_to_matrix(sums, U);
+        }
+        mat4_mul(U, T, T);
+        const double pf = fit, pr = rmse;
+        if ((rc = eval(T))) return rc;
+        fit = sums[0] / (double)ns;
+        rmse = sums[0] > 0 ? sqrt(sums[1] / sums[0]) : 0.0;
+        if (fabs(pf - fit) < p->relative_fitness && fabs(pr - rmse) < p->relative_rmse) { converged = 1; break; }
+    }
+    if (it > max_it) it = max_it;
+    memcpy(T4x4, T, sizeof T);
+    if (stats) {
+        stats->iterations = it;
+        stats->converged = converged;
+        stats->correspondences = (int64_t)sums[0];
+        stats->fitness = fit;
+        stats->inlier_rmse = rmse;
+    }
+    return R3D_OK;
+}
+
+}  // extern "C"

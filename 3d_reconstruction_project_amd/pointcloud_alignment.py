@@ -1,0 +1,64 @@
+"""Drop-in for the reference's pointcloud_alignment.py (class PointCloudAlignment, method align_point_clouds) and
+for the GICP flavour of the same step in test/GICP1.py:81-104.  Same signature, same prints, same return value
+(the DOWN-SAMPLED, transformed source); the Open3D calls are replaced by the HIP kernels behind include/r3d.h."""
+import numpy as np
+
+from . import cloud_ops
+from .pointcloud import as_arrays, like
+
+
+class PointCloudAlignment:
+    def __init__(self, verbose=True, method="point_to_point"):
+        self.verbose = verbose
+        self.method = method
+        self.last_result = None
+
+    def align_point_clouds(self, source, target, threshold=0.02, voxel_size=0.01, max_iter=100):
+        """pointcloud_alignment.py:6-43: voxel_down_sample both clouds, estimate_normals(Hybrid(2*voxel, 30)) on both,
+        registration_icp(PointToPoint, criteria(1e-6, 1e-6, max_iter)) from identity, transform the source."""
+        sp, sc, _ = as_arrays(source)
+        tp, tc, _ = as_arrays(target)
+        if self.verbose:
+            print("Downsampling point clouds using voxel size:", voxel_size)
+        sp, sc, _ = cloud_ops.voxel_down_sample(sp, voxel_size, sc)
+        tp, tc, _ = cloud_ops.voxel_down_sample(tp, voxel_size, tc)
+        if self.verbose:
+            print("Estimating normals on CPU...")          # the reference's own (inaccurate) message, kept verbatim
+        sn = cloud_ops.estimate_normals(sp, voxel_size * 2, 30)
+        tn = cloud_ops.estimate_normals(tp, voxel_size * 2, 30)
+        if self.verbose:
+            print("Performing ICP alignment using CUDA...")
+        mode = {"point_to_point": cloud_ops.P2P, "point_to_plane": cloud_ops.P2PLANE, "gicp": cloud_ops.GICP}[self.method]
+        res = cloud_ops.registration(sp, tp, threshold, np.eye(4), mode, max_iter, 1e-6, 1e-6, sn, tn)
+        self.last_result = res
+        T = res["T"]
+        return like(source, cloud_ops.transform_points(sp, T), sc, cloud_ops.transform_points(sn, T, rotate_only=True))
+
+    # north_star alias
+    align = align_point_clouds
+
+
+class GeneralizedICPAlignment:
+    """test/GICP1.py:81-104 align_point_clouds(source, target, threshold=0.02): normals Hybrid(0.05, 30) if missing,
+    registration_generalized_icp with default criteria (30 iterations), source.transform."""
+
+    def __init__(self):
+        self.last_result = None
+
+    def align_point_clouds(self, source, target, threshold=0.02):
+        sp, sc, sn = as_arrays(source)
+        tp, _, tn = as_arrays(target)
+        if sn is None:
+            sn = cloud_ops.estimate_normals(sp, 0.05, 30)
+        if tn is None:
+            tn = cloud_ops.estimate_normals(tp, 0.05, 30)
+        res = cloud_ops.registration(sp, tp, threshold, np.eye(4), cloud_ops.GICP, 30, 1e-6, 1e-6, sn, tn)
+        self.last_result = res
+        T = res["T"]
+        return like(source, cloud_ops.transform_points(sp, T), sc, cloud_ops.transform_points(sn, T, rotate_only=True))
+
+    align = align_point_clouds
+
+
+def align(source, target, **kw):
+    return PointCloudAlignment(verbose=False).align_point_clouds(source, target, **kw)

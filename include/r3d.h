@@ -93,6 +93,62 @@ int r3d_sgbm_profile(r3d_ctx *ctx, float *ms, int32_t max_slots, char *names, in
  *   raw    int16 [h][w]       disparity after the row LR check, before the 3x3 median */
 int r3d_sgbm_debug_fetch(r3d_ctx *ctx, int16_t *cost, int16_t *hsum, int16_t *raw);
 
+/* ---- point clouds (float64 xyz triplets, like the legacy open3d.geometry.PointCloud the reference passes) ----- */
+
+/* replaces: pcd.voxel_down_sample(voxel_size)   pointcloud_alignment.py:22-23, test/check84.py:180
+ * origin = min_bound - voxel/2, key = floor((p-origin)/voxel); out = per-voxel mean of points (and colors /
+ * normals when given; pass NULL otherwise).  Output arrays need room for n triplets; *out_n = voxels written, in
+ * lexicographic key order (the original's order is hash-map order, i.e. unspecified). */
+int r3d_voxel_downsample(r3d_ctx *ctx, const double *xyz, const double *colors, const double *normals, int64_t n, double voxel,
+                         double *out_xyz, double *out_colors, double *out_normals, int64_t *out_n);
+
+/* replaces: pcd.estimate_normals(KDTreeSearchParamHybrid(radius, max_nn))   pointcloud_alignment.py:27-28,
+ * test/GICP1.py:77,95,97,148; tensor estimate_normals(max_nn, radius)   normal_estimation.py:20.
+ * radius <= 0 selects KDTreeSearchParamKNN(max_nn).  <= max_nn nearest neighbours with distance < radius (query
+ * included), population covariance, unit eigenvector of the smallest eigenvalue; fewer than 3 neighbours -> (0,0,1).
+ * prev_normals (may be NULL): when given, each normal is flipped to agree with it (legacy behaviour). */
+int r3d_estimate_normals(r3d_ctx *ctx, const double *xyz, int64_t n, double radius, int32_t max_nn, const double *prev_normals,
+                         double *normals);
+
+/* per-point neighbourhood score used by remove_statistical_outlier / remove_radius_outlier
+ * (pointcloud_processing.py:35,39; test/check_lama1.py:175): count_radius <= 0: mean distance to the k nearest
+ * points, the point itself included; count_radius > 0: number of points within that radius, itself included. */
+int r3d_neighbor_score(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, double count_radius, double *score);
+
+/* k-nearest-neighbour graph (indices in the caller's numbering, nearest first, the point itself first; missing
+ * entries -1 / 1e300).  radius <= 0: unbounded.  Feeds orient_normals_consistent_tangent_plane(k)
+ * (normal_estimation.py:21), whose spanning-tree propagation is sequential host work.  d2 may be NULL. */
+int r3d_knn_graph(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, double radius, int32_t *nbr, double *d2);
+
+/* replaces: pcd.transform(T)   pointcloud_alignment.py:42  (rotate_only != 0 for normals) ; T row-major 4x4 */
+int r3d_transform_points(r3d_ctx *ctx, const double *xyz, int64_t n, const double *T4x4, int32_t rotate_only, double *out);
+
+/* replaces: o3d.pipelines.registration.registration_icp(source, target, max_dist, init, PointToPoint / PointToPlane,
+ *           ICPConvergenceCriteria(relative_fitness, relative_rmse, max_iteration))   pointcloud_alignment.py:35-39,
+ *           test/check2.py:151-154;  registration_generalized_icp(...)   test/GICP1.py:99-102 */
+#define R3D_ICP_POINT_TO_POINT 0
+#define R3D_ICP_POINT_TO_PLANE 1
+#define R3D_ICP_GENERALIZED 2
+typedef struct {
+    int32_t mode;
+    int32_t max_iteration;              /* Open3D default 30; pointcloud_alignment.py passes 100 */
+    double max_correspondence_distance; /* 1-NN accepted iff distance < this */
+    double relative_fitness;            /* 1e-6 */
+    double relative_rmse;               /* 1e-6 */
+    double gicp_epsilon;                /* 1e-3; <= 0 selects the default */
+} r3d_icp_params;
+typedef struct {
+    int32_t iterations; /* ComputeTransformation calls performed */
+    int32_t converged;  /* stopped by the relative criteria (not an error when 0) */
+    int64_t correspondences;
+    double fitness;     /* correspondences / source points */
+    double inlier_rmse; /* Euclidean, over correspondences */
+} r3d_icp_stats;
+/* src_normals: GICP only (covariances C = I - (1-eps) n n^T, as Open3D derives them from normals);
+ * tgt_normals: point-to-plane and GICP.  init4x4 may be NULL (identity).  T4x4: row-major result. */
+int r3d_icp(r3d_ctx *ctx, const r3d_icp_params *p, const double *src, int64_t ns, const double *src_normals, const double *tgt,
+            int64_t nt, const double *tgt_normals, const double *init4x4, double *T4x4, r3d_icp_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

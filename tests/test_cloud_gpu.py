@@ -1,0 +1,196 @@
+"""GPU parity tests of the point-cloud kernels (through the C ABI) against the oracle and the recorded fixtures.
+Tolerances: voxel means / SOR membership bit-exact; normals 1e-6 sign-agnostic (fixture PLYs) ; registration
+transforms 1e-8 against the float64 oracle (north_star bar: 1e-3 on coordinates / normals)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cloud_oracle as co
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+INTR = co.read_intrinsics(os.path.join(GOLDEN, "camera_intrinsic.json"))
+
+
+def _sorted(p, *rest):
+    o = np.lexsort(p.T[::-1])
+    return (p[o],) + tuple(r[o] for r in rest)
+
+
+def _frame(sub, i):
+    d = co.read_png16(os.path.join(GOLDEN, f"{sub}/depth_{i:05d}.png"))
+    return co.backproject(d, INTR)[0]
+
+
+def _sign_agnostic_err(a, b):
+    return np.minimum(np.abs(a - b).max(1), np.abs(a + b).max(1))
+
+
+@pytest.mark.parametrize("frame", [8, 11])
+def test_voxel_downsample_reproduces_recorded_ply(r3d, frame):
+    pts = _frame("output84", frame)
+    ply = co.read_ply(os.path.join(GOLDEN, f"output84/pcd_{frame:05d}.ply"))
+    got, _, _ = r3d.cloud_ops.voxel_down_sample(pts, 0.02)
+    a, = _sorted(got)
+    b, = _sorted(ply["points"])
+    assert a.shape == b.shape and np.abs(a - b).max() == 0.0
+    # and it already comes out in lexicographic voxel-key order == the oracle's order
+    np.testing.assert_array_equal(got, co.voxel_down_sample(pts, 0.02))
+
+
+def test_voxel_downsample_colors_and_small_voxels(r3d):
+    from PIL import Image
+    d = co.read_png16(os.path.join(GOLDEN, "output84/depth_00008.png"))
+    col = np.asarray(Image.open(os.path.join(GOLDEN, "output84/color_00008.png")))
+    pts, (v, u) = co.backproject(d, INTR)
+    c = col[v, u] / 255.0
+    for voxel in (0.02, 0.01, 0.0025):
+        gp, gc, _ = r3d.cloud_ops.voxel_down_sample(pts, voxel, colors=c)
+        wp, wc = co.voxel_down_sample(pts, voxel, colors=c)
+        np.testing.assert_array_equal(gp, wp)
+        np.testing.assert_array_equal(gc, wc)
+
+
+@pytest.mark.parametrize("sub,k", [("output84", 20), ("output", 30)])
+def test_hybrid_normals_reproduce_recorded_ply(r3d, sub, k):
+    ply = co.read_ply(os.path.join(GOLDEN, f"{sub}/pcd_00008.ply"))
+    n = r3d.cloud_ops.estimate_normals(ply["points"], 0.04, k)
+    err = _sign_agnostic_err(n, ply["normals"])
+    assert err.max() < 1e-6 and np.median(err) < 1e-10
+    assert np.abs(np.linalg.norm(n, axis=1) - 1).max() < 1e-12
+    # previous normals fix the sign (legacy EstimateNormals keeps the old orientation)
+    n2 = r3d.cloud_ops.estimate_normals(ply["points"], 0.04, k, prev_normals=ply["normals"])
+    assert np.abs(n2 - ply["normals"]).max() < 1e-6
+
+
+def test_knn_normals_and_sparse_points(r3d):
+    pts = co.voxel_down_sample(_frame("output84", 9), 0.01)
+    got = r3d.cloud_ops.estimate_normals(pts, None, 20)
+    want = co.estimate_normals_knn(pts, 20)
+    assert _sign_agnostic_err(got, want).max() < 1e-6
+    far = np.array([[0, 0, 0], [5, 5, 5.0], [5.001, 5, 5], [9, 9, 9.0], [0.001, 0, 0], [0, 0.001, 0], [0.0005, 0.0005, 0.001]])
+    n = r3d.cloud_ops.estimate_normals(far, 0.01, 30)
+    assert (n[[1, 2, 3]] == [0, 0, 1]).all()                 # fewer than 3 neighbours in range
+
+
+def test_statistical_and_radius_outlier_masks(r3d):
+    pts = co.voxel_down_sample(_frame("output", 8), 0.02)
+    got = r3d.cloud_ops.statistical_outlier_mask(pts, 20, 2.0)
+    np.testing.assert_array_equal(got, co.statistical_outlier_mask(pts, 20, 2.0))
+    ply = co.read_ply(os.path.join(GOLDEN, "output/pcd_00008.ply"))
+    a, = _sorted(pts[got])
+    b, = _sorted(ply["points"])
+    assert a.shape == b.shape and np.abs(a - b).max() == 0.0     # == the reference's recorded result
+    np.testing.assert_array_equal(r3d.cloud_ops.radius_outlier_mask(pts, 4, 0.03), co.radius_outlier_mask(pts, 4, 0.03))
+
+
+def test_knn_graph_matches_kdtree(r3d):
+    from scipy.spatial import cKDTree
+    pts = co.voxel_down_sample(_frame("output84", 10), 0.02)
+    nbr, d2 = r3d.cloud_ops.knn_graph(pts, 16)
+    d, idx = cKDTree(pts).query(pts, k=16)
+    assert np.abs(np.sqrt(d2) - d).max() < 1e-12
+    assert (nbr == idx).mean() > 0.999                           # equal up to exact-distance ties
+    assert (nbr[:, 0] == np.arange(len(pts))).all()
+
+
+def test_transform_points(r3d, synth):
+    rng = np.random.default_rng(0)
+    p = rng.normal(size=(1000, 3))
+    T = synth.rigid((1, 2, 3), 33.0, (0.1, -0.2, 0.3))
+    assert np.abs(r3d.cloud_ops.transform_points(p, T) - co.transform_points(T, p)).max() < 1e-14
+    assert np.abs(r3d.cloud_ops.transform_points(p, T, rotate_only=True) - p @ T[:3, :3].T).max() < 1e-14
+
+
+def _sphere(n, seed, r=1.0):
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal((n, 3))
+    return r * v / np.linalg.norm(v, axis=1, keepdims=True)
+
+
+def test_p2p_exact_recovery(r3d, synth):
+    src = _sphere(4000, 0, 0.5) * np.array([1.0, 0.8, 0.6])
+    T = synth.rigid((0.3, -0.5, 0.8), 0.2, (0.001, -0.0015, 0.0008))
+    res = r3d.cloud_ops.registration(src, co.transform_points(T, src), 0.02, mode=0, max_iteration=30)
+    assert np.abs(res["T"] - T).max() < 1e-10 and res["fitness"] == 1.0 and res["inlier_rmse"] < 1e-10
+
+
+@pytest.mark.parametrize("mode,name", [(0, "p2p"), (1, "p2plane"), (2, "gicp")])
+def test_registration_matches_oracle_iteration_for_iteration(r3d, synth, mode, name):
+    rng = np.random.default_rng(3)
+    sc = np.array([1.0, 0.7, 0.5])
+    tgt = _sphere(20000, 1, 0.3) * sc + rng.normal(0, 2e-4, (20000, 3))
+    T = synth.rigid((0.3, -0.5, 0.8), 1.0, (0.004, -0.002, 0.003))
+    src = co.transform_points(np.linalg.inv(T), _sphere(15000, 2, 0.3) * sc + rng.normal(0, 2e-4, (15000, 3)))
+    tn = co.estimate_normals_knn(tgt, 20)
+    sn = co.estimate_normals_knn(src, 20)
+    kw = {}
+    if name != "p2p":
+        kw["target_normals"] = tn
+    if name == "gicp":
+        kw["target_cov"] = co.covariances_from_normals(tn)
+        kw["source_cov"] = co.covariances_from_normals(sn)
+    for max_it in (1, 3, 40):
+        want = co.registration(src, tgt, 0.02, mode=name, max_iteration=max_it, **kw)
+        got = r3d.cloud_ops.registration(src, tgt, 0.02, mode=mode, max_iteration=max_it, source_normals=sn, target_normals=tn)
+        assert got["iterations"] == want["iterations"]
+        assert got["correspondences"] == want["correspondences"]
+        assert abs(got["fitness"] - want["fitness"]) < 1e-12 and abs(got["inlier_rmse"] - want["inlier_rmse"]) < 1e-9
+        assert np.abs(got["T"] - want["T"]).max() < 1e-8
+    # and the converged answer is the right one
+    R_err = got["T"][:3, :3] @ T[:3, :3].T
+    ang = np.degrees(np.arccos(np.clip((np.trace(R_err) - 1) / 2, -1, 1)))
+    assert ang < (0.7 if name == "p2p" else 0.05)
+
+
+def test_registration_with_initial_guess_and_no_overlap(r3d, synth):
+    src = _sphere(3000, 5, 0.2)
+    T = synth.rigid((0, 0, 1), 5.0, (0.05, 0.0, 0.0))
+    tgt = co.transform_points(T, src)
+    init = synth.rigid((0, 0, 1), 4.8, (0.049, 0.0005, 0.0))
+    got = r3d.cloud_ops.registration(src, tgt, 0.01, init=init, mode=0, max_iteration=30)
+    want = co.registration(src, tgt, 0.01, init=init, mode="p2p", max_iteration=30)
+    assert np.abs(got["T"] - want["T"]).max() < 1e-8 and got["iterations"] == want["iterations"]
+    far = r3d.cloud_ops.registration(src, tgt + 10.0, 0.01, mode=0, max_iteration=5)
+    assert far["fitness"] == 0.0 and far["correspondences"] == 0 and np.abs(far["T"] - np.eye(4)).max() == 0
+
+
+def test_align_point_clouds_drop_in(r3d, capsys):
+    """main.py:48 calls align_point_clouds(frame, combined) positionally; result = down-sampled transformed source."""
+    src, tgt = _frame("output84", 9), _frame("output84", 8)
+    pa = r3d.PointCloudAlignment()
+    out = pa.align_point_clouds(r3d.PointCloud(src), r3d.PointCloud(tgt))
+    printed = capsys.readouterr().out
+    assert "Downsampling point clouds using voxel size: 0.01" in printed and "Performing ICP alignment" in printed
+    s = co.voxel_down_sample(src, 0.01)
+    t = co.voxel_down_sample(tgt, 0.01)
+    want = co.registration(s, t, 0.02, mode="p2p", max_iteration=100)
+    assert pa.last_result["iterations"] == want["iterations"]
+    assert np.abs(pa.last_result["T"] - want["T"]).max() < 1e-8
+    assert np.abs(np.asarray(out.points) - co.transform_points(want["T"], s)).max() < 1e-8   # bar: 1e-3
+    assert out.has_normals() and len(out.points) == len(s)
+    # GICP flavour (test/GICP1.py:81-104)
+    g = r3d.GeneralizedICPAlignment()
+    sp = r3d.PointCloud(s)
+    tp = r3d.PointCloud(t)
+    out2 = g.align_point_clouds(sp, tp)
+    sn, tn = co.estimate_normals_hybrid(s, 0.05, 30), co.estimate_normals_hybrid(t, 0.05, 30)
+    want2 = co.registration(s, t, 0.02, mode="gicp", max_iteration=30, target_normals=tn,
+                            target_cov=co.covariances_from_normals(tn), source_cov=co.covariances_from_normals(sn))
+    assert g.last_result["iterations"] == want2["iterations"]
+    assert np.abs(np.asarray(out2.points) - co.transform_points(want2["T"], s)).max() < 1e-6
+
+
+def test_normal_estimation_drop_in(r3d):
+    """normal_estimation.py:12-22 on a fixture cloud: fp32-rounded coordinates, k<=50 within 0.05, then orientation."""
+    pts = co.voxel_down_sample(_frame("output84", 8), 0.01)
+    out = r3d.NormalEstimation("CUDA:0").estimate_normals(r3d.PointCloud(pts))
+    p32 = pts.astype(np.float32).astype(np.float64)
+    want = co.estimate_normals_hybrid(p32, 0.05, 50)
+    n = np.asarray(out.normals)
+    assert _sign_agnostic_err(n, want).max() < 1e-5
+    # orientation: neighbouring normals agree after propagation (a depth-camera surface is one open sheet)
+    from scipy.spatial import cKDTree
+    _, idx = cKDTree(p32).query(p32, k=2)
+    assert ((n * n[idx[:, 1]]).sum(1) > 0).mean() > 0.98
