@@ -157,10 +157,17 @@ __device__ __forceinline__ int knn_query(const GridView &g, double qx, double qy
                 double dx = g.pts[(int64_t)i * 3] - qx, dy = g.pts[(int64_t)i * 3 + 1] - qy, dz = g.pts[(int64_t)i * 3 + 2] - qz;
                 double d2 = dx * dx + dy * dy + dz * dz;
                 if (!(d2 < r2)) continue;
-                if (cnt == k && !(d2 < sd[(k - 1) * KNN_BLOCK + t])) continue;
+                // total order (d2, original index): exact-distance ties are common on voxelised / fp32-rounded clouds,
+                // and the oracle breaks them the same way
+                if (cnt == k) {
+                    const double worst = sd[(k - 1) * KNN_BLOCK + t];
+                    if (d2 > worst || (d2 == worst && g.idx[i] > g.idx[si[(k - 1) * KNN_BLOCK + t]])) continue;
+                }
                 int pos = cnt < k ? cnt : k - 1;
-                while (pos > 0 && sd[(pos - 1) * KNN_BLOCK + t] > d2) {
-                    sd[pos * KNN_BLOCK + t] = sd[(pos - 1) * KNN_BLOCK + t];
+                while (pos > 0) {
+                    const double pd = sd[(pos - 1) * KNN_BLOCK + t];
+                    if (!(pd > d2 || (pd == d2 && g.idx[si[(pos - 1) * KNN_BLOCK + t]] > g.idx[i]))) break;
+                    sd[pos * KNN_BLOCK + t] = pd;
                     si[pos * KNN_BLOCK + t] = si[(pos - 1) * KNN_BLOCK + t];
                     pos--;
                 }
@@ -249,9 +256,14 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_normals(GridView g, int64_t n, in
                         zz * inv - sz * sz, nrm);
     }
     const int64_t o = g.idx[i];
-    if (prev) {
-        if (nrm[0] * prev[o * 3] + nrm[1] * prev[o * 3 + 1] + nrm[2] * prev[o * 3 + 2] < 0) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
+    bool flip;
+    if (prev) flip = nrm[0] * prev[o * 3] + nrm[1] * prev[o * 3 + 1] + nrm[2] * prev[o * 3 + 2] < 0;
+    else {  // sign convention (an eigenvector's sign is solver-dependent): largest-magnitude component positive
+        const double ax = fabs(nrm[0]), ay = fabs(nrm[1]), az = fabs(nrm[2]);
+        const double lead = (ax >= ay && ax >= az) ? nrm[0] : (ay >= az ? nrm[1] : nrm[2]);
+        flip = lead < 0;
     }
+    if (flip) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
     normals[o * 3] = nrm[0]; normals[o * 3 + 1] = nrm[1]; normals[o * 3 + 2] = nrm[2];
     if (nn_count) nn_count[o] = cnt;
 }
@@ -358,7 +370,7 @@ __global__ void __launch_bounds__(ICP_BLOCK) k_icp_eval(GridView g, const double
                 for (int j = b; j < e; j++) {
                     double dx = g.pts[(int64_t)j * 3] - px, dy = g.pts[(int64_t)j * 3 + 1] - py, dz = g.pts[(int64_t)j * 3 + 2] - pz;
                     double d2 = dx * dx + dy * dy + dz * dz;
-                    if (d2 < best) { best = d2; bi = j; }
+                    if (d2 < best || (d2 == best && bi >= 0 && g.idx[j] < g.idx[bi])) { best = d2; bi = j; }
                 }
             });
             const double reach = s * g.cell;

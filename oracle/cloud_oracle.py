@@ -123,6 +123,19 @@ def radius_outlier_mask(points, nb_points, radius):
 
 
 # --------------------------------------------------------------------------------------------------- normals
+def _canon_sign(v):
+    """Sign convention shared with the HIP kernel (an eigenvector's sign is solver-dependent; the reference's own
+    sign is Open3D's solver's, unknowable here): the largest-magnitude component is positive."""
+    a = np.abs(v)
+    lead = v[0] if (a[0] >= a[1] and a[0] >= a[2]) else (v[1] if a[1] >= a[2] else v[2])
+    return -v if lead < 0 else v
+
+
+def _d2(points, idx, q):
+    d = points[idx] - q
+    return (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+
+
 def _pca_normals(points, idx_lists):
     n = points.shape[0]
     normals = np.zeros((n, 3))
@@ -136,19 +149,29 @@ def _pca_normals(points, idx_lists):
         c = np.cov(q.T, bias=True)
         covs[i] = c
         w, v = np.linalg.eigh(c)
-        normals[i] = v[:, 0]
+        normals[i] = _canon_sign(v[:, 0])
     return normals, covs
+
+
+def _nearest_total_order(points, q, k, extra=12):
+    """k nearest of every query under the TOTAL ORDER (squared distance, index): exact-distance ties are common on
+    voxelised clouds and a kd-tree breaks them arbitrarily.  Returns (idx [m,k], d2 [m,k])."""
+    kk = min(k + extra, points.shape[0])
+    _, idx = cKDTree(points).query(q, k=kk)
+    if kk == 1:
+        idx = idx[:, None]
+    d2 = _d2(points, idx, q[:, None, :])
+    order = np.lexsort((idx, d2), axis=1)
+    idx = np.take_along_axis(idx, order, 1)[:, :k]
+    d2 = np.take_along_axis(d2, order, 1)[:, :k]
+    return idx, d2
 
 
 def hybrid_neighbors(points, radius, max_nn, queries=None):
     """<= max_nn nearest neighbours with distance < radius (self included), nearest first."""
-    tree = cKDTree(points)
     q = points if queries is None else queries
-    k = min(max_nn, points.shape[0])
-    d, idx = tree.query(q, k=k)
-    if k == 1:
-        d, idx = d[:, None], idx[:, None]
-    keep = d < radius
+    idx, d2 = _nearest_total_order(points, q, min(max_nn, points.shape[0]))
+    keep = d2 < radius * radius
     return [idx[i][keep[i]] for i in range(q.shape[0])]
 
 
@@ -159,7 +182,7 @@ def estimate_normals_hybrid(points, radius, max_nn):
 
 
 def estimate_normals_knn(points, k):
-    _, idx = cKDTree(points).query(points, k=min(k, points.shape[0]))
+    idx, _ = _nearest_total_order(points, points, min(k, points.shape[0]))
     return _pca_normals(points, list(idx))[0]
 
 
@@ -213,12 +236,19 @@ def covariances_from_normals(normals, eps=1e-3):
 
 def _evaluate(src, tree, max_dist):
     """GetRegistrationResultAndCorrespondences: 1-NN with dist < max_dist; fitness, inlier RMSE (Euclidean)."""
-    d, j = tree.query(src, k=1)
-    ok = d < max_dist
+    tgt = tree.data
+    _, cand = tree.query(src, k=min(4, tgt.shape[0]))
+    if cand.ndim == 1:
+        cand = cand[:, None]
+    d2 = _d2(tgt, cand, src[:, None, :])
+    order = np.lexsort((cand, d2), axis=1)[:, 0]                 # total order (d2, index), as the HIP kernel
+    j = np.take_along_axis(cand, order[:, None], 1)[:, 0]
+    d2 = np.take_along_axis(d2, order[:, None], 1)[:, 0]
+    ok = d2 < max_dist * max_dist
     i = np.nonzero(ok)[0]
     if i.size == 0:
         return i, j[ok], 0.0, 0.0
-    return i, j[ok], i.size / src.shape[0], float(np.sqrt((d[ok] ** 2).sum() / i.size))
+    return i, j[ok], i.size / src.shape[0], float(np.sqrt(d2[ok].sum() / i.size))
 
 
 def _inv_sqrt_sym(M):

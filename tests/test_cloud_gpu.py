@@ -89,10 +89,15 @@ def test_knn_graph_matches_kdtree(r3d):
     from scipy.spatial import cKDTree
     pts = co.voxel_down_sample(_frame("output84", 10), 0.02)
     nbr, d2 = r3d.cloud_ops.knn_graph(pts, 16)
-    d, idx = cKDTree(pts).query(pts, k=16)
+    d, _ = cKDTree(pts).query(pts, k=16)
     assert np.abs(np.sqrt(d2) - d).max() < 1e-12
-    assert (nbr == idx).mean() > 0.999                           # equal up to exact-distance ties
+    idx, wd2 = co._nearest_total_order(pts, pts, 16)              # ties broken by (distance, index) on both sides
+    np.testing.assert_array_equal(nbr, idx)
+    np.testing.assert_array_equal(d2, wd2)
     assert (nbr[:, 0] == np.arange(len(pts))).all()
+    pts32 = pts.astype(np.float32).astype(np.float64)            # fp32-rounded coordinates: many exact ties
+    nbr, _ = r3d.cloud_ops.knn_graph(pts32, 24)
+    np.testing.assert_array_equal(nbr, co._nearest_total_order(pts32, pts32, 24)[0])
 
 
 def test_transform_points(r3d, synth):
