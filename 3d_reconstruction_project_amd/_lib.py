@@ -26,7 +26,8 @@ class IcpParams(ctypes.Structure):
 
 class IcpStats(ctypes.Structure):
     _fields_ = [("iterations", ctypes.c_int32), ("converged", ctypes.c_int32), ("correspondences", ctypes.c_int64),
-                ("fitness", ctypes.c_double), ("inlier_rmse", ctypes.c_double)]
+                ("fitness", ctypes.c_double), ("inlier_rmse", ctypes.c_double), ("setup_ms", ctypes.c_double),
+                ("loop_ms", ctypes.c_double)]
 
 
 _lib = None

@@ -106,4 +106,5 @@ def registration(source, target, max_correspondence_distance, init=None, mode=P2
     ctx.call("r3d_icp", ctypes.byref(prm), _ptr(s), len(s), _ptr(sn), _ptr(t), len(t), _ptr(tn), _ptr(T0), _ptr(T),
              ctypes.byref(st))
     return dict(T=T, fitness=st.fitness, inlier_rmse=st.inlier_rmse, iterations=st.iterations,
-                converged=bool(st.converged), correspondences=st.correspondences)
+                converged=bool(st.converged), correspondences=st.correspondences, setup_ms=st.setup_ms,
+                loop_ms=st.loop_ms)

@@ -14,6 +14,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -873,6 +874,7 @@ int r3d_icp(r3d_ctx *ctx, const r3d_icp_params *p, const double *src, int64_t ns
     if (p->mode != MODE_P2P && !tgt_normals) return r3d_fail(ctx, R3D_E_BADARG, "icp: target normals required for this mode");
     if (p->mode == MODE_GICP && !src_normals) return r3d_fail(ctx, R3D_E_BADARG, "icp: source normals required for GICP");
     R3D_HIP(ctx, hipSetDevice(ctx->device));
+    const auto t_begin = std::chrono::steady_clock::now();
     DevArena ar(ctx);
     int rc;
     double *d_t, *d_tn = nullptr, *d_s, *d_sn = nullptr;
@@ -930,6 +932,8 @@ int r3d_icp(r3d_ctx *ctx, const r3d_icp_params *p, const double *src, int64_t ns
         R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return R3D_OK;
     };
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t_loop = std::chrono::steady_clock::now();
     if ((rc = eval(T))) return rc;
     double fit = sums[0] / (double)ns, rmse = sums[0] > 0 ? sqrt(sums[1] / sums[0]) : 0.0;
     int it = 0, converged = 0;
@@ -956,6 +960,9 @@ int r3d_icp(r3d_ctx *ctx, const r3d_icp_params *p, const double *src, int64_t ns
         stats->correspondences = (int64_t)sums[0];
         stats->fitness = fit;
         stats->inlier_rmse = rmse;
+        const auto t_end = std::chrono::steady_clock::now();
+        stats->setup_ms = std::chrono::duration<double, std::milli>(t_loop - t_begin).count();
+        stats->loop_ms = std::chrono::duration<double, std::milli>(t_end - t_loop).count();
     }
     return R3D_OK;
 }

@@ -31,12 +31,53 @@ ALG_BYTES = {
 }
 
 
+def bench_gicp(r3d, ctx, n=1_000_000, iters=20, cpu=True):
+    """Secondary metric of BASELINE.json (config C3): GICP iterations/s on a 1M-point cloud pair, normals from
+    kNN(20) PCA (the 'no normals' GICP branch), exactly `iters` iterations (criteria set so they never trigger),
+    one-off setup (uploads, grid build, normals) reported separately.  SURVEY.md 8d: 80 B/source point + cell table
+    = 88 MB algorithmic per iteration."""
+    import numpy as np
+    co = r3d.cloud_ops
+    src, tgt, T_star = r3d.synth.cloud_pair(n)
+    src, tgt = src.astype(np.float64), tgt.astype(np.float64)
+    t0 = time.perf_counter()
+    sn = co.estimate_normals(src, None, 20, ctx=ctx)
+    tn = co.estimate_normals(tgt, None, 20, ctx=ctx)
+    normals_s = time.perf_counter() - t0
+    co.registration(src, tgt, 0.02, mode=co.GICP, max_iteration=2, relative_fitness=-1, relative_rmse=-1,
+                    source_normals=sn, target_normals=tn, ctx=ctx)                        # warm-up (allocations)
+    res = co.registration(src, tgt, 0.02, mode=co.GICP, max_iteration=iters, relative_fitness=-1, relative_rmse=-1,
+                          source_normals=sn, target_normals=tn, ctx=ctx)
+    per_iter_ms = res["loop_ms"] / (iters + 1)               # iters+1 evaluate launches, iters solves
+    err = float(np.linalg.norm(res["T"] - T_star))
+    alg = 88e6
+    out = {"metric": "GICP iterations/s @1M pts", "value": round(1e3 / per_iter_ms, 2), "unit": "iterations/s",
+           "iterations": res["iterations"], "ms_per_iteration": round(per_iter_ms, 4),
+           "setup_ms": {"normals_knn20_both_clouds": round(1e3 * normals_s, 1), "grid_sort_upload": round(res["setup_ms"], 1)},
+           "fitness": round(res["fitness"], 5), "inlier_rmse": res["inlier_rmse"], "T_error_frobenius": err,
+           "roofline": {"bound": "hbm", "achieved": round(alg / (per_iter_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK / 1e9,
+                        "unit": "GB/s", "frac": round(alg / (per_iter_ms * 1e-3) / HBM_PEAK, 5), "traffic": None}}
+    if cpu:
+        from oracle import cloud_oracle as oc               # checker timed as the CPU baseline ("port")
+        k = 2
+        tc = time.perf_counter()
+        oc.registration(src, tgt, 0.02, mode="gicp", max_iteration=k, relative_fitness=-1, relative_rmse=-1,
+                        target_normals=tn, target_cov=oc.covariances_from_normals(tn),
+                        source_cov=oc.covariances_from_normals(sn))
+        dt = time.perf_counter() - tc
+        out["cpu_baseline"] = {"value": round((k + 1) / dt, 3), "unit": "iterations/s", "cores": 1, "kind": "port",
+                               "sample": f"{k} iterations ({k + 1} evaluations) at 1M points, numpy/scipy cKDTree restatement "
+                                         "of Open3D registration_generalized_icp (oracle/cloud_oracle.py)"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gicp", action="store_true", help="skip the secondary metric (GICP iterations/s at 1M points)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,6 +153,9 @@ def main():
             cpu = {"value": round(n / dt, 3), "unit": "disparity-maps/s", "cores": threads, "kind": "port",
                    "sample": f"{n} full 3264x2448 D=128 maps, C restatement of OpenCV StereoSGBM 3WAY "
                              f"(oracle/sgbm3way.c, -O3 AVX2), host has {os.cpu_count()} cpus"}
+        gicp = None
+        if world == 1 and not args.no_gicp:
+            gicp = bench_gicp(r3d, ctx, cpu=not args.no_cpu_baseline)
         out = {"metric": "disparity-maps/s @8MP d=128", "value": round(value, 2), "unit": "disparity-maps/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
@@ -119,7 +163,7 @@ def main():
                "config": {"workload": "C2: 3264x2448 rectified pair, numDisparities=128, blockSize=5, "
                                       "MODE_SGBM_3WAY (depth2.py params), one pair per GPU resident in HBM",
                           "parallelism": f"dp{world} (one view per GPU, no collective in the SGM step)"},
-               "roofline": roofline, "cpu_baseline": cpu}
+               "roofline": roofline, "cpu_baseline": cpu, "secondary": gicp}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

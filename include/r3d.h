@@ -143,6 +143,8 @@ typedef struct {
     int64_t correspondences;
     double fitness;     /* correspondences / source points */
     double inlier_rmse; /* Euclidean, over correspondences */
+    double setup_ms;    /* host wall time: uploads, target grid build, source sort */
+    double loop_ms;     /* host wall time of the evaluate / solve loop (iterations + 1 evaluations) */
 } r3d_icp_stats;
 /* src_normals: GICP only (covariances C = I - (1-eps) n n^T, as Open3D derives them from normals);
  * tgt_normals: point-to-plane and GICP.  init4x4 may be NULL (identity).  T4x4: row-major result. */
