@@ -4,7 +4,7 @@ The directory name starts with a digit (it mirrors the upstream project name), s
     import importlib; r3d = importlib.import_module("3d_reconstruction_project_amd")
 or through the `r3d` alias module at the repository root (`import r3d`).
 """
-from . import (_lib, cloud_ops, io_formats, normal_estimation, orientation, pointcloud, pointcloud_alignment,  # noqa: F401
+from . import (_lib, cloud_ops, distributed, io_formats, pipeline, normal_estimation, orientation, pointcloud, pointcloud_alignment,  # noqa: F401
                pointcloud_processing, stereo_sgbm, synth)
 from ._lib import Context, R3DError, default_context  # noqa: F401
 from .stereo_sgbm import (STEREO_SGBM_MODE_SGBM_3WAY, StereoSGBM, StereoSGBM_create, depth,  # noqa: F401

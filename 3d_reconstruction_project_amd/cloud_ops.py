@@ -13,6 +13,8 @@ _lib.register({
                               ctypes.POINTER(ctypes.c_int64)], ctypes.c_int),
     "r3d_estimate_normals": ([_vp, _vp, ctypes.c_int64, ctypes.c_double, ctypes.c_int32, _vp, _vp], ctypes.c_int),
     "r3d_neighbor_score": ([_vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_double, _vp], ctypes.c_int),
+    "r3d_reproject_disparity": ([_vp, _vp, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _vp,
+                                 ctypes.POINTER(ctypes.c_int64)], ctypes.c_int),
     "r3d_knn_graph": ([_vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_double, _vp, _vp], ctypes.c_int),
     "r3d_transform_points": ([_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int32, _vp], ctypes.c_int),
     "r3d_icp": ([_vp, ctypes.POINTER(_lib.IcpParams), _vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp,
@@ -61,6 +63,21 @@ def neighbor_score(points, k=0, count_radius=0.0, ctx=None):
     out = np.empty(len(p))
     ctx.call("r3d_neighbor_score", _ptr(p), len(p), int(k), float(count_radius), out.ctypes.data_as(_vp))
     return out
+
+
+def reproject_disparity(disp, Q, min_disparity=0, want_pixels=False, ctx=None):
+    """disp: int16 [H,W] (x16, as StereoSGBM.compute returns it); Q: 4x4.  Returns points [M,3] (and pixel indices)."""
+    ctx = ctx or _lib.default_context()
+    d = np.ascontiguousarray(disp, dtype=np.int16)
+    H, W = d.shape
+    Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(4, 4)
+    out = np.empty((H * W, 3))
+    pix = np.empty(H * W, np.int32) if want_pixels else None
+    m = ctypes.c_int64()
+    ctx.call("r3d_reproject_disparity", d.ctypes.data_as(_vp), W, H, _ptr(Q), int(min_disparity) * 16, _ptr(out),
+             pix.ctypes.data_as(_vp) if want_pixels else None, ctypes.byref(m))
+    out = out[:m.value].copy()
+    return (out, pix[:m.value].copy()) if want_pixels else out
 
 
 def knn_graph(points, k, radius=0.0, want_d2=True, ctx=None):

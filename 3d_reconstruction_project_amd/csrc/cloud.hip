@@ -479,6 +479,28 @@ __global__ void __launch_bounds__(256) k_transform(const double *__restrict__ in
     out[i * 3 + 2] = T.r[6] * x + T.r[7] * y + T.r[8] * z + tz;
 }
 
+// ------------------------------------------------------------------------------------------------ disparity -> cloud
+// cv2.reprojectImageTo3D semantics: [X Y Z W]^T = Q [x y d 1]^T, point = (X, Y, Z) / W with d = disp / 16;
+// pixels with disp < min_valid (the matcher's invalid marker and anything below minDisparity) are dropped.
+__global__ void __launch_bounds__(256) k_disp_flags(const int16_t *__restrict__ disp, int64_t n, int min_valid, int *__restrict__ flags) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flags[i] = disp[i] >= min_valid ? 1 : 0;
+}
+struct Mat4 { double m[16]; };
+__global__ void __launch_bounds__(256) k_reproject(const int16_t *__restrict__ disp, const int *__restrict__ flags, const int *__restrict__ scan,
+                                                   int w, int64_t n, Mat4 Q, double *__restrict__ xyz, int *__restrict__ pix) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    const double x = (double)(i % w), y = (double)(i / w), d = (double)disp[i] / 16.0;
+    const double X = Q.m[0] * x + Q.m[1] * y + Q.m[2] * d + Q.m[3];
+    const double Y = Q.m[4] * x + Q.m[5] * y + Q.m[6] * d + Q.m[7];
+    const double Z = Q.m[8] * x + Q.m[9] * y + Q.m[10] * d + Q.m[11];
+    const double W = Q.m[12] * x + Q.m[13] * y + Q.m[14] * d + Q.m[15];
+    const int64_t o = scan[i];
+    xyz[o * 3] = X / W; xyz[o * 3 + 1] = Y / W; xyz[o * 3 + 2] = Z / W;
+    if (pix) pix[o] = (int)i;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 struct DevArena {  // simple bump allocator over ctx->cloud_bufs (grow-only, reused across calls)
     r3d_ctx *ctx;
@@ -820,6 +842,45 @@ int r3d_neighbor_score(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, do
     k_knn_score<<<(unsigned)((n + KNN_BLOCK - 1) / KNN_BLOCK), KNN_BLOCK, lds, ctx->stream>>>(G.v, n, kk, count_radius, d_s);
     R3D_HIP(ctx, hipGetLastError());
     R3D_HIP(ctx, hipMemcpyAsync(score, d_s, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return R3D_OK;
+}
+
+int r3d_reproject_disparity(r3d_ctx *ctx, const int16_t *disp, int32_t w, int32_t h, const double *Q4x4, int32_t min_valid_x16,
+                            double *out_xyz, int32_t *out_pixel, int64_t *out_n) {
+    if (!ctx) return R3D_E_BADARG;
+    if (!disp || !Q4x4 || !out_xyz || !out_n || w <= 0 || h <= 0) return r3d_fail(ctx, R3D_E_BADARG, "reproject_disparity: bad argument");
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    DevArena ar(ctx);
+    const int64_t n = (int64_t)w * h;
+    if (n > 0x7fffffff) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "reproject_disparity: image too large");
+    int16_t *d_d = (int16_t *)ar.get((size_t)n * 2);
+    int *flags = (int *)ar.get((size_t)n * 4), *scan = (int *)ar.get((size_t)n * 4);
+    if (ar.rc) return ar.rc;
+    R3D_HIP(ctx, hipMemcpyAsync(d_d, disp, (size_t)n * 2, hipMemcpyHostToDevice, ctx->stream));
+    const int nb = (int)((n + 255) / 256);
+    k_disp_flags<<<nb, 256, 0, ctx->stream>>>(d_d, n, min_valid_x16, flags);
+    size_t tb = 0;
+    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flags, scan, (int)n, ctx->stream));
+    void *tmp = ar.get(tb);
+    if (ar.rc) return ar.rc;
+    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tb, flags, scan, (int)n, ctx->stream));
+    int ls = 0, lf = 0;
+    R3D_HIP(ctx, hipMemcpyAsync(&ls, scan + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipMemcpyAsync(&lf, flags + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t m = (int64_t)ls + lf;
+    *out_n = m;
+    if (m == 0) return R3D_OK;
+    double *d_xyz = (double *)ar.get((size_t)m * 24);
+    int *d_pix = out_pixel ? (int *)ar.get((size_t)m * 4) : nullptr;
+    if (ar.rc) return ar.rc;
+    Mat4 Q;
+    memcpy(Q.m, Q4x4, sizeof Q.m);
+    k_reproject<<<nb, 256, 0, ctx->stream>>>(d_d, flags, scan, w, n, Q, d_xyz, d_pix);
+    R3D_HIP(ctx, hipGetLastError());
+    R3D_HIP(ctx, hipMemcpyAsync(out_xyz, d_xyz, (size_t)m * 24, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_pixel) R3D_HIP(ctx, hipMemcpyAsync(out_pixel, d_pix, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
     R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return R3D_OK;
 }

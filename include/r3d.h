@@ -115,6 +115,13 @@ int r3d_estimate_normals(r3d_ctx *ctx, const double *xyz, int64_t n, double radi
  * points, the point itself included; count_radius > 0: number of points within that radius, itself included. */
 int r3d_neighbor_score(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, double count_radius, double *score);
 
+/* disparity map -> point cloud, cv2.reprojectImageTo3D semantics ([X Y Z W]^T = Q [x y disp/16 1]^T, point = XYZ/W).
+ * The reference computes / loads Q (Calib_depth/depth1.py:169,183, depth2.py:49,66) but never calls reprojectImageTo3D;
+ * this is the join between its two halves.  Pixels with disp < min_valid_x16 are dropped;
+ * out_xyz needs room for w*h triplets, out_pixel (may be NULL) receives the row-major pixel index of each point. */
+int r3d_reproject_disparity(r3d_ctx *ctx, const int16_t *disp, int32_t w, int32_t h, const double *Q4x4, int32_t min_valid_x16,
+                            double *out_xyz, int32_t *out_pixel, int64_t *out_n);
+
 /* k-nearest-neighbour graph (indices in the caller's numbering, nearest first, the point itself first; missing
  * entries -1 / 1e300).  radius <= 0: unbounded.  Feeds orient_normals_consistent_tangent_plane(k)
  * (normal_estimation.py:21), whose spanning-tree propagation is sequential host work.  d2 may be NULL. */

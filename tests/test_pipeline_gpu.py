@@ -1,0 +1,65 @@
+"""GPU tests of the orchestration layer: disparity->cloud, the frame-fusion loop (BASELINE config C4 on fixture
+frames) and the single-rank path of the multi-view fusion."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cloud_oracle as co
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+INTR = co.read_intrinsics(os.path.join(GOLDEN, "camera_intrinsic.json"))
+
+
+def test_reproject_disparity_matches_formula(r3d):
+    Q = np.load(os.path.join(GOLDEN, "jetson_stereo_8MP_stereo.npz"))["Q"]
+    rng = np.random.default_rng(0)
+    disp = rng.integers(-16, 128 * 16, (120, 200)).astype(np.int16)
+    disp[:, :16] = -16
+    pts, pix = r3d.cloud_ops.reproject_disparity(disp, Q, 0, want_pixels=True)
+    v, u = np.nonzero(disp >= 0)
+    np.testing.assert_array_equal(pix, v * 200 + u)                                  # row-major order, valid only
+    d = disp[v, u] / 16.0
+    h = np.stack([u, v, d, np.ones_like(d)], 0).astype(np.float64)
+    X = (Q[:, 0:1] * h[0] + Q[:, 1:2] * h[1]) + Q[:, 2:3] * h[2] + Q[:, 3:4] * h[3]
+    want = (X[:3] / X[3]).T
+    finite = np.isfinite(want).all(1)
+    assert np.abs(pts[finite] - want[finite]).max() <= 1e-9 * np.abs(want[finite]).max()
+    empty = r3d.cloud_ops.reproject_disparity(np.full((10, 20), -16, np.int16), Q, 0)
+    assert empty.shape == (0, 3)
+
+
+def test_fuse_loop_matches_oracle_on_fixture_frames(r3d):
+    """main.py:34-54 on recorded frames 8..11 (config C4, shortened): first frame initialises the model, later frames
+    are aligned to the growing model with align_point_clouds(threshold=0.02, voxel_size=0.01, max_iter=100)."""
+    frames = []
+    for i in (8, 9, 10, 11):
+        d = co.read_png16(os.path.join(GOLDEN, f"output84/depth_{i:05d}.png"))
+        frames.append(co.voxel_down_sample(co.backproject(d, INTR)[0], 0.01))
+    got = r3d.pipeline.fuse([r3d.PointCloud(f) for f in frames] + [None, r3d.PointCloud()], flavour="icp")
+    model = frames[0]
+    for f in frames[1:]:
+        s = co.voxel_down_sample(f, 0.01)
+        t = co.voxel_down_sample(model, 0.01)
+        T = co.registration(s, t, 0.02, mode="p2p", max_iteration=100)["T"]
+        model = np.concatenate([model, co.transform_points(T, s)], 0)
+    assert got.points.shape == model.shape
+    assert np.abs(got.points - model).max() < 1e-6                     # bar: 1e-3
+
+
+def test_view_to_cloud_and_single_rank_multi_view(r3d, synth):
+    W, H, D = 640, 480, 64
+    Q = r3d.pipeline.scaled_Q(np.load(os.path.join(GOLDEN, "jetson_stereo_8MP_stereo.npz"))["Q"], W / 960.0)
+    m = r3d.reference_matcher(numDisparities=D, blockSize=5)
+    clouds = {}
+    poses = {0: np.eye(4), 1: synth.rigid((0, 1, 0), 0.4, (0.003, -0.002, 0.001))}
+    for v in (0, 1):
+        L, R, _ = synth.stereo_pair(W, H, D, seed=100 + v)
+        clouds[v] = r3d.pipeline.view_to_cloud(L, R, Q, m, voxel=0.004, pose=np.linalg.inv(poses[v]))
+        assert clouds[v].has_normals() and len(clouds[v]) > 2000
+    fused, Ts = r3d.pipeline.multi_view_fuse(clouds, 2, threshold=0.02)
+    assert len(fused) == len(clouds[0]) + len(clouds[1])
+    R_err = Ts[1][:3, :3] @ poses[1][:3, :3].T
+    ang = np.degrees(np.arccos(np.clip((np.trace(R_err) - 1) / 2, -1, 1)))
+    assert ang < 0.2 and np.abs(Ts[1][:3, 3] - poses[1][:3, 3]).max() < 2e-3
