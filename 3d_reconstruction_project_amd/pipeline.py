@@ -37,12 +37,14 @@ def fuse(frames, flavour="icp", verbose=False, **align_kw):
     return model
 
 
-def scaled_Q(Q, scale):
-    """Q of the 960x540 rig (tests/golden/jetson_stereo_8MP_stereo.npz) re-expressed for images `scale` times larger."""
+def scaled_Q(Q, scale, unit=1.0):
+    """Q of the 960x540 rig (tests/golden/jetson_stereo_8MP_stereo.npz) re-expressed for images `scale` times larger.
+    The rig was calibrated in millimetres (baseline 31.5): unit=1e-3 yields metres, the unit of the scanner half."""
     Q = np.array(Q, dtype=np.float64)
     Q[0, 3] *= scale
     Q[1, 3] *= scale
     Q[2, 3] *= scale
+    Q[:3] *= unit
     return Q
 
 

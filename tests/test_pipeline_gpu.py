@@ -50,7 +50,7 @@ def test_fuse_loop_matches_oracle_on_fixture_frames(r3d):
 
 def test_view_to_cloud_and_single_rank_multi_view(r3d, synth):
     W, H, D = 640, 480, 64
-    Q = r3d.pipeline.scaled_Q(np.load(os.path.join(GOLDEN, "jetson_stereo_8MP_stereo.npz"))["Q"], W / 960.0)
+    Q = r3d.pipeline.scaled_Q(np.load(os.path.join(GOLDEN, "jetson_stereo_8MP_stereo.npz"))["Q"], W / 960.0, unit=1e-3)
     m = r3d.reference_matcher(numDisparities=D, blockSize=5)
     clouds = {}
     poses = {0: np.eye(4), 1: synth.rigid((0, 1, 0), 0.4, (0.003, -0.002, 0.001))}
