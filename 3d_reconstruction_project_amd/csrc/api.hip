@@ -87,7 +87,7 @@ void r3d_destroy(r3d_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    r3d_buf *bufs[] = {&ctx->img_l, &ctx->img_r, &ctx->rec_l, &ctx->rec_r, &ctx->cost, &ctx->cspec, &ctx->hsum,
+    r3d_buf *bufs[] = {&ctx->img_l, &ctx->img_r, &ctx->rec_l, &ctx->rec_r, &ctx->cost, &ctx->cspec, &ctx->hsum, &ctx->ckpt,
                        &ctx->raw, &ctx->mins, &ctx->lrd, &ctx->out, &ctx->flags};
     for (r3d_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);

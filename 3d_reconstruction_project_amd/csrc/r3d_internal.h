@@ -30,7 +30,7 @@ struct r3d_ctx {
     std::string err;
     bool profiling = false;
     // grow-only workspace
-    r3d_buf img_l, img_r, rec_l, rec_r, cost, cspec, hsum, raw, mins, lrd, out, flags;
+    r3d_buf img_l, img_r, rec_l, rec_r, cost, cspec, hsum, ckpt, raw, mins, lrd, out, flags;
     // geometry of the last sgbm call (for debug fetch)
     int last_w = 0, last_h = 0, last_w1 = 0, last_dp = 0;
     // profiling: ring of event sets so that harvesting never stalls the stream; sums accumulate per kernel name

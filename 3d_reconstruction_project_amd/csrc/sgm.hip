@@ -14,6 +14,9 @@
 // Lane mapping of every volume kernel: one wavefront owns ONE (row, column) disparity vector; lane l holds the
 // 2*NP consecutive disparities d = 2*NP*l .. 2*NP*l+2*NP-1 as NP packed int16x2 registers, so a wave reads or
 // writes 256*NP contiguous bytes per pixel and the d-1 / d+1 neighbours come from one DPP wave shift each way.
+#include <stdlib.h>
+#include <string.h>
+
 #include "r3d_internal.h"
 
 namespace {
@@ -88,6 +91,89 @@ __device__ __forceinline__ void sgm_step(int (&P)[NP], int &minp, const int (&C)
 #pragma unroll
     for (int j = 0; j < NP; j++) P[j] = Q[j];
     minp = wave_allmin_i32(m32);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Generic lane mapping (v2 kernels): a disparity vector of DP = 2*NPL*LPC entries is spread over LPC adjacent lanes,
+// NPL packed registers (2*NPL consecutive disparities) per lane, so one wave holds 64/LPC independent vectors.
+// Cross-lane work (2 DPP shifts + log2(LPC) butterfly stages) is amortised over NPL registers.
+template <int LPC>
+__device__ __forceinline__ int grp_shr1(int v, int fill, bool first) {  // lane i <- lane i-1 inside its LPC-lane group
+    if constexpr (LPC == 1) return fill;
+    else if constexpr (LPC == 64) return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
+    else if constexpr (LPC == 32) { int t = __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); return first ? fill : t; }
+    else { int t = __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xf, 0xf, false); return (LPC < 16 && first) ? fill : t; }
+}
+template <int LPC>
+__device__ __forceinline__ int grp_shl1(int v, int fill, bool last) {   // lane i <- lane i+1 inside its group
+    if constexpr (LPC == 1) return fill;
+    else if constexpr (LPC == 64) return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false);
+    else if constexpr (LPC == 32) { int t = __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); return last ? fill : t; }
+    else { int t = __builtin_amdgcn_update_dpp(fill, v, 0x101, 0xf, 0xf, false); return (LPC < 16 && last) ? fill : t; }
+}
+// all-reduce min inside each LPC-lane group; `old` = identity so that the DPP move folds into v_min_i32_dpp
+template <int LPC>
+__device__ __forceinline__ int grp_allmin(int v) {
+    if constexpr (LPC >= 2) v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0xB1, 0xf, 0xf, false));
+    if constexpr (LPC >= 4) v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x4E, 0xf, 0xf, false));
+    if constexpr (LPC >= 8) v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x141, 0xf, 0xf, false));
+    if constexpr (LPC >= 16) v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x140, 0xf, 0xf, false));
+    if constexpr (LPC >= 32) { auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); v = min((int)r[0], (int)r[1]); }
+    if constexpr (LPC >= 64) { auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false); v = min((int)r[0], (int)r[1]); }
+    return v;
+}
+template <int LPC>
+__device__ __forceinline__ int grp_allsum(int v) {
+    if constexpr (LPC >= 2) v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+    if constexpr (LPC >= 4) v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+    if constexpr (LPC >= 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
+    if constexpr (LPC >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
+    if constexpr (LPC >= 32) { auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); v = (int)r[0] + (int)r[1]; }
+    if constexpr (LPC >= 64) { auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false); v = (int)r[0] + (int)r[1]; }
+    return v;
+}
+
+// same recurrence as sgm_step, generic mapping; minp is uniform inside a group
+template <int NPL, int LPC>
+__device__ __forceinline__ void sgm_step_g(int (&P)[NPL], int &minp, const int (&C)[NPL], int P1pk, int P2, bool first, bool last,
+                                           bool lane_valid) {
+    const int mp2 = pk_dup(minp + P2);
+    const int up = grp_shr1<LPC>(P[NPL - 1], PADPK, first);
+    const int dn = grp_shl1<LPC>(P[0], PADPK, last);
+    int Q[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        const int below = j == 0 ? up : P[j - 1];
+        const int above = j == NPL - 1 ? dn : P[j + 1];
+        const int A = __builtin_amdgcn_alignbit(P[j], below, 16);
+        const int B = __builtin_amdgcn_alignbit(above, P[j], 16);
+        const int nb = pk_add_sat(pk_min(A, B), P1pk);
+        const int m = pk_min(pk_min(P[j], mp2), nb);
+        const int q = pk_add(C[j], pk_sub(m, mp2));
+        Q[j] = lane_valid ? q : PADPK;
+    }
+    int m = Q[0];
+#pragma unroll
+    for (int j = 1; j < NPL; j++) m = pk_min(m, Q[j]);
+#pragma unroll
+    for (int j = 0; j < NPL; j++) P[j] = Q[j];
+    minp = grp_allmin<LPC>(min(lo16(m), hi16(m)));
+}
+
+// trunc(n / d) for d > 0, |n|, d < 2^23: float reciprocal estimate + exact integer correction
+__device__ __forceinline__ int trunc_div_small(int n, int d) {
+    int q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
+    int r = n - q * d;
+    if (n >= 0) { if (r < 0) q--; else if (r >= d) q++; }
+    else { if (r > 0) q++; else if (r <= -d) q--; }
+    return q;
+}
+// smallest integer T with T * a >= thr  (a > 0): S * a < thr  <=>  S < T
+__device__ __forceinline__ int ceil_div_small(int thr, int a, float inv_a) {
+    int q = (int)floorf((float)thr * inv_a);
+    while (q * a < thr) q++;
+    while ((q - 1) * a >= thr) q--;
+    return q;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -414,6 +500,219 @@ __global__ void __launch_bounds__(64) k_vscan(const int *__restrict__ cvol, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// k_hscan2: one wave per image row, NO spill of L_left to HBM.
+//   phase 1: forward chain over the row; the state entering every K-column segment is check-pointed (8 B/lane);
+//   phase 2: segments right-to-left: the segment's C values are loaded ONCE into registers, the forward chain is
+//            recomputed from the checkpoint (L_left of the segment stays in registers), then the backward chain
+//            runs over the same registers and streams L_left + L_right to HBM.
+// HBM traffic per row: C read twice, sum written once, + 2 * 8 B * 64 * W1/K of checkpoints (6 % at K = 32).
+// A tail of W1 % K columns uses the v1 scheme (L_left parked in the output row).
+template <int NP, int K>
+__global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int *__restrict__ hvol, int *__restrict__ ckpt, SgmGeom g) {
+    constexpr int NPW = NP * 64, CKW = (NP + 1) * 64;
+    const int lane = threadIdx.x, y = blockIdx.x;
+    const int *crow = cvol + (size_t)y * g.W1 * NPW + lane * NP;
+    int *hrow = hvol + (size_t)y * g.W1 * NPW + lane * NP;
+    const int W1 = g.W1, nfull = W1 / K, P1pk = pk_dup(g.P1);
+    int *ck = ckpt + (size_t)y * (nfull + 1) * CKW + lane * (NP + 1);
+    const bool valid = 2 * NP * lane < g.D, first = lane == 0, last = lane == 63;
+    int P[NP], minp = 0;
+    int cA[K][NP], cB[K][NP], ll[K][NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) P[j] = valid ? 0 : PADPK;
+    auto load_seg = [&](int (&buf)[K][NP], int sidx) {
+        const int sc = min(max(sidx, 0), max(nfull - 1, 0));
+        const int *p = crow + (size_t)sc * K * NPW;
+#pragma unroll
+        for (int u = 0; u < K; u++)
+#pragma unroll
+            for (int j = 0; j < NP; j++) buf[u][j] = p[(size_t)u * NPW + j];
+    };
+    auto save_ck = [&](int sidx) {
+#pragma unroll
+        for (int j = 0; j < NP; j++) ck[(size_t)sidx * CKW + j] = P[j];
+        ck[(size_t)sidx * CKW + NP] = minp;
+    };
+    // ---- phase 1
+    if (nfull > 0) {
+        load_seg(cA, 0);
+        for (int s0 = 0; s0 < nfull; s0 += 2) {
+            load_seg(cB, s0 + 1);
+            save_ck(s0);
+#pragma unroll
+            for (int u = 0; u < K; u++) sgm_step_g<NP, 64>(P, minp, cA[u], P1pk, g.P2, first, last, valid);
+            if (s0 + 1 < nfull) {
+                load_seg(cA, s0 + 2);
+                save_ck(s0 + 1);
+#pragma unroll
+                for (int u = 0; u < K; u++) sgm_step_g<NP, 64>(P, minp, cB[u], P1pk, g.P2, first, last, valid);
+            }
+        }
+    }
+    // tail columns [nfull*K, W1): forward values parked in the output row
+    for (int x = nfull * K; x < W1; x++) {
+        int c[NP];
+#pragma unroll
+        for (int j = 0; j < NP; j++) c[j] = crow[(size_t)x * NPW + j];
+        sgm_step_g<NP, 64>(P, minp, c, P1pk, g.P2, first, last, valid);
+#pragma unroll
+        for (int j = 0; j < NP; j++) hrow[(size_t)x * NPW + j] = P[j];
+    }
+    // ---- phase 2
+    int R[NP], minr = 0;
+#pragma unroll
+    for (int j = 0; j < NP; j++) R[j] = valid ? 0 : PADPK;
+    for (int x = W1 - 1; x >= nfull * K; x--) {
+        int c[NP];
+#pragma unroll
+        for (int j = 0; j < NP; j++) c[j] = crow[(size_t)x * NPW + j];
+        sgm_step_g<NP, 64>(R, minr, c, P1pk, g.P2, first, last, valid);
+#pragma unroll
+        for (int j = 0; j < NP; j++) hrow[(size_t)x * NPW + j] = pk_add(hrow[(size_t)x * NPW + j], R[j]);
+    }
+    auto run_seg = [&](int (&cb)[K][NP], int sidx) {
+#pragma unroll
+        for (int j = 0; j < NP; j++) P[j] = ck[(size_t)sidx * CKW + j];
+        minp = ck[(size_t)sidx * CKW + NP];
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            sgm_step_g<NP, 64>(P, minp, cb[u], P1pk, g.P2, first, last, valid);
+#pragma unroll
+            for (int j = 0; j < NP; j++) ll[u][j] = P[j];
+        }
+        int *hp = hrow + (size_t)sidx * K * NPW;
+#pragma unroll
+        for (int u = K - 1; u >= 0; u--) {
+            sgm_step_g<NP, 64>(R, minr, cb[u], P1pk, g.P2, first, last, valid);
+#pragma unroll
+            for (int j = 0; j < NP; j++) hp[(size_t)u * NPW + j] = pk_add(ll[u][j], R[j]);
+        }
+    };
+    if (nfull > 0) {
+        load_seg(cA, nfull - 1);
+        for (int s0 = nfull - 1; s0 >= 0; s0 -= 2) {
+            load_seg(cB, s0 - 1);
+            run_seg(cA, s0);
+            if (s0 - 1 >= 0) {
+                load_seg(cA, s0 - 2);
+                run_seg(cB, s0 - 1);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_vscan2: vertical path + winner-take-all with 16 disparities per lane (NPL = 8): LPC = DP/16 lanes per column,
+// CPW = 64/LPC adjacent columns per wave, each column an independent chain inside its lane group.  Everything after
+// the path step -- argmin (32-bit keys cost<<16|d, v_min3 tree + group butterfly), uniqueness (packed compare against
+// the per-column threshold, counted), sub-pixel (the two neighbours of the winner are fetched through a per-wave LDS
+// image of S) -- is per-lane VALU work: no scalar unit traffic, no serialisation over columns.
+template <int LPC>
+__global__ void __launch_bounds__(64) k_vscan2(const int *__restrict__ cvol, const int *__restrict__ cspec,
+                                               const int *__restrict__ hvol, SgmGeom g, float inv_a, int16_t *__restrict__ raw,
+                                               int16_t *__restrict__ mins) {
+    constexpr int NPL = 8, CPW = 64 / LPC, DPW = NPL * LPC;  // DPW words per column
+    __shared__ int sS[64 * NPL];
+    const int lane = threadIdx.x, k = lane % LPC, grp = lane / LPC, n = blockIdx.y;
+    const int xc = blockIdx.x * CPW + grp;
+    const bool col_ok = xc < g.W1;
+    const size_t rowWords = (size_t)g.W1 * DPW;
+    const int src_start = max(min(n * g.stripe_sz - g.overlap, g.H), 0);
+    const int src_end = min((n + 1) * g.stripe_sz, g.H);
+    const int out_start = min(n * g.stripe_sz, g.H);
+    if (src_start >= src_end) return;
+    const bool valid = 16 * k < g.D, first = k == 0, last = k == LPC - 1;
+    const int P1pk = pk_dup(g.P1);
+    const size_t off = (size_t)min(xc, g.W1 - 1) * DPW + k * NPL;
+    const int a = 100 - g.uniq;
+    int P[NPL], minp = 0;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) P[j] = valid ? 0 : PADPK;
+    int cc[NPL], hh[NPL], cn[NPL], hn[NPL];
+    auto load_row = [&](int y, int (&cb)[NPL], int (&hb)[NPL]) {
+        const int yy = min(y, src_end - 1);
+        const int *cr = ((n > 0 && yy < src_start + g.SH2) ? cspec + ((size_t)(n - 1) * g.SH2 + (yy - src_start)) * rowWords
+                                                             : cvol + (size_t)yy * rowWords) + off;
+        const int4 c0 = *(const int4 *)cr, c1 = *(const int4 *)(cr + 4);
+        cb[0] = c0.x; cb[1] = c0.y; cb[2] = c0.z; cb[3] = c0.w; cb[4] = c1.x; cb[5] = c1.y; cb[6] = c1.z; cb[7] = c1.w;
+        if (yy >= out_start) {
+            const int *hr = hvol + (size_t)yy * rowWords + off;
+            const int4 h0 = *(const int4 *)hr, h1 = *(const int4 *)(hr + 4);
+            hb[0] = h0.x; hb[1] = h0.y; hb[2] = h0.z; hb[3] = h0.w; hb[4] = h1.x; hb[5] = h1.y; hb[6] = h1.z; hb[7] = h1.w;
+        }
+    };
+    auto process = [&](int y, int (&cb)[NPL], int (&hb)[NPL]) {
+        sgm_step_g<NPL, LPC>(P, minp, cb, P1pk, g.P2, first, last, valid);
+        if (y < out_start) return;
+        int S[NPL];
+        int key = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < NPL; j++) {
+            S[j] = pk_add_sat(hb[j], P[j]);
+            const int d0 = 16 * k + 2 * j;
+            const int k0 = (int)((unsigned)S[j] << 16) | d0;              // (cost of d0) << 16 | d0, signed order
+            const int k1 = (S[j] & (int)0xffff0000) | (d0 + 1);
+            key = min(key, min(k0, k1));
+        }
+        if (!valid) key = 0x7fffffff;
+        key = grp_allmin<LPC>(key);
+        const int best = key & 0xffff, minS = key >> 16;
+        // per-wave LDS image of S: the winner's neighbours are read back with a per-lane (per-column) address
+        __syncthreads();
+        *(int4 *)&sS[lane * NPL] = make_int4(S[0], S[1], S[2], S[3]);
+        *(int4 *)&sS[lane * NPL + 4] = make_int4(S[4], S[5], S[6], S[7]);
+        __syncthreads();
+        const int gbase = (lane - k) * NPL;
+        const int dm = max(best - 1, 0), dp = min(best + 1, g.D - 1);
+        const int wm = sS[gbase + (dm >> 1)], wp = sS[gbase + (dp >> 1)];
+        const int sm = (dm & 1) ? hi16(wm) : lo16(wm), sp = (dp & 1) ? hi16(wp) : lo16(wp);
+        bool bad = false;
+        if (g.uniq > 0) {
+            // S*a < minS*100  <=>  S < T ; count the disparities below T, subtract those inside [best-1, best+1]
+            const int T = ceil_div_small(minS * 100, a, inv_a);
+            int cnt;
+            if (T > 32767) cnt = valid ? 16 : 0;
+            else {
+                const int Tpk = pk_dup(max(T, -32768));
+                int acc = 0;
+#pragma unroll
+                for (int j = 0; j < NPL; j++) {
+                    const int diff = as_i(__builtin_elementwise_sub_sat(as_s(S[j]), as_s(Tpk)));   // < 0  <=>  S < T
+                    acc = pk_sub(acc, as_i(as_s(diff) >> (s16x2){15, 15}));                        // += 1 per negative half
+                }
+                cnt = valid ? lo16(acc) + hi16(acc) : 0;
+            }
+            cnt = grp_allsum<LPC>(cnt);
+            int win = (minS < T) ? 1 : 0;
+            if (best > 0 && sm < T) win++;
+            if (best < g.D - 1 && sp < T) win++;
+            bad = cnt > win;
+        }
+        int dsp = g.invalid;
+        if (!bad) {
+            dsp = best * 16;
+            if (0 < best && best < g.D - 1) {
+                const int den = max(sm + sp - 2 * minS, 1);
+                dsp += trunc_div_small((sm - sp) * 16 + den, den * 2);
+            }
+            dsp += g.minD * 16;
+        }
+        if (first && col_ok) {
+            const size_t o = (size_t)y * g.W + g.minX1 + xc;
+            raw[o] = (int16_t)dsp;
+            mins[o] = (int16_t)minS;
+        }
+    };
+    load_row(src_start, cc, hh);
+    for (int y = src_start; y < src_end; y += 2) {
+        load_row(y + 1, cn, hn);
+        process(y, cc, hh);
+        load_row(y + 2, cc, hh);
+        if (y + 1 < src_end) process(y + 1, cn, hn);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // k_lrcheck: per row: rebuild OpenCV's disp2 / disp2cost scatter (lowest cost wins, among equal costs the
 // LARGEST x, because the original sweeps x right-to-left with a strict '>') with one LDS atomicMin on the key
 // (cost+32768)<<16 | (w-1-x), then apply the two-sided disp12MaxDiff test.  Output covers all w columns.
@@ -515,6 +814,29 @@ __global__ void __launch_bounds__(64) k_selftest(int *out) {
         int wm = wave_allmin_i32(min(want[0], want[1]));
         if (minp != wm) bad |= 2048;
     }
+    // generic group helpers (v2 kernels), LPC = 8 and 16
+    {
+        auto val = [](int l) { return (l * 37 + 11) % 101 - 50; };
+        const int k8 = lane % 8, k16 = lane % 16;
+        if (grp_shr1<8>(v, -777, k8 == 0) != (k8 == 0 ? -777 : val(lane - 1))) bad |= 1 << 12;
+        if (grp_shl1<8>(v, -777, k8 == 7) != (k8 == 7 ? -777 : val(lane + 1))) bad |= 1 << 13;
+        if (grp_shr1<16>(v, -777, k16 == 0) != (k16 == 0 ? -777 : val(lane - 1))) bad |= 1 << 14;
+        if (grp_shl1<16>(v, -777, k16 == 15) != (k16 == 15 ? -777 : val(lane + 1))) bad |= 1 << 15;
+        int m8 = 1 << 30, s8 = 0, m16 = 1 << 30, s16 = 0;
+        for (int l = lane - k8; l < lane - k8 + 8; l++) { m8 = min(m8, val(l)); s8 += val(l); }
+        for (int l = lane - k16; l < lane - k16 + 16; l++) { m16 = min(m16, val(l)); s16 += val(l); }
+        if (grp_allmin<8>(v) != m8) bad |= 1 << 16;
+        if (grp_allsum<8>(v) != s8) bad |= 1 << 17;
+        if (grp_allmin<16>(v) != m16) bad |= 1 << 18;
+        if (grp_allsum<16>(v) != s16) bad |= 1 << 19;
+        if (grp_allmin<64>(v) != mn) bad |= 1 << 20;
+        // exact small divisions
+        const int nn = (lane - 31) * 4099 + 7, dd = 2 * (lane * 37 + 1);
+        if (trunc_div_small(nn, dd) != nn / dd) bad |= 1 << 21;
+        const int thr = (lane - 20) * 997 * 100, aa = 85;
+        int T = ceil_div_small(thr, aa, 1.0f / 85.0f);
+        if (!(T * aa >= thr && (T - 1) * aa < thr)) bad |= 1 << 22;
+    }
     atomicOr(out, bad);
 }
 
@@ -541,6 +863,7 @@ int derive_geom(r3d_ctx *ctx, const r3d_sgbm_params *p, int w, int h, SgmGeom &g
     g.P2 = p->P2 > 0 ? p->P2 : 5;
     if (g.P2 < g.P1 + 1) g.P2 = g.P1 + 1;
     g.uniq = p->uniquenessRatio >= 0 ? p->uniquenessRatio : 10;
+    if (g.uniq >= 100) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "sgbm: uniquenessRatio >= 100 not supported (got %d)", g.uniq);
     g.d12 = p->disp12MaxDiff > 0 ? p->disp12MaxDiff : 1;
     g.ftzero = (p->preFilterCap > 15 ? p->preFilterCap : 15) | 1;
     g.stripe_sz = (h + 3) / 4;
@@ -621,9 +944,18 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
         }
         R3D_HIP(ctx, hipGetLastError());
     }
+    static const bool use_v1 = [] { const char *e = getenv("R3D_SGM_IMPL"); return e && !strcmp(e, "v1"); }();
     r3d_prof_mark(ctx, "hscan");
-    if (g.NP == 1) k_hscan<1><<<h, 64, 0, st>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, g);
-    else k_hscan<2><<<h, 64, 0, st>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, g);
+    if (use_v1) {
+        if (g.NP == 1) k_hscan<1><<<h, 64, 0, st>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, g);
+        else k_hscan<2><<<h, 64, 0, st>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, g);
+    } else {
+        constexpr int K1 = 32, K2 = 16;
+        const int K = g.NP == 1 ? K1 : K2;
+        if ((rc = r3d_reserve(ctx, ctx->ckpt, (size_t)h * (g.W1 / K + 1) * (g.NP + 1) * 64 * 4))) return rc;
+        if (g.NP == 1) k_hscan2<1, K1><<<h, 64, 0, st>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, (int *)ctx->ckpt.p, g);
+        else k_hscan2<2, K2><<<h, 64, 0, st>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, (int *)ctx->ckpt.p, g);
+    }
     R3D_HIP(ctx, hipGetLastError());
 
     r3d_prof_mark(ctx, "vscan_wta");
@@ -631,7 +963,11 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
     {
         constexpr int CPW = 8;
         dim3 grid((g.W1 + CPW - 1) / CPW, 4);
-        if (g.NP == 1) k_vscan<1, CPW><<<grid, 64, 0, st>>>((const int *)ctx->cost.p, (const int *)ctx->cspec.p, (const int *)ctx->hsum.p, g, (int16_t *)ctx->raw.p, (int16_t *)ctx->mins.p);
+        const float inv_a = 1.0f / (float)(100 - g.uniq);
+        if (!use_v1) {
+            if (g.NP == 1) k_vscan2<8><<<dim3((g.W1 + 7) / 8, 4), 64, 0, st>>>((const int *)ctx->cost.p, (const int *)ctx->cspec.p, (const int *)ctx->hsum.p, g, inv_a, (int16_t *)ctx->raw.p, (int16_t *)ctx->mins.p);
+            else k_vscan2<16><<<dim3((g.W1 + 3) / 4, 4), 64, 0, st>>>((const int *)ctx->cost.p, (const int *)ctx->cspec.p, (const int *)ctx->hsum.p, g, inv_a, (int16_t *)ctx->raw.p, (int16_t *)ctx->mins.p);
+        } else if (g.NP == 1) k_vscan<1, CPW><<<grid, 64, 0, st>>>((const int *)ctx->cost.p, (const int *)ctx->cspec.p, (const int *)ctx->hsum.p, g, (int16_t *)ctx->raw.p, (int16_t *)ctx->mins.p);
         else k_vscan<2, CPW><<<grid, 64, 0, st>>>((const int *)ctx->cost.p, (const int *)ctx->cspec.p, (const int *)ctx->hsum.p, g, (int16_t *)ctx->raw.p, (int16_t *)ctx->mins.p);
         R3D_HIP(ctx, hipGetLastError());
     }
