@@ -320,6 +320,142 @@ __global__ void __launch_bounds__(COST_NW * 64) k_cost(const uint2 *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// k_cost2: same result as k_cost, restructured for the vector pipes (v1 was bound by the scalar ALU: ~35 SALU per
+// column step, and every load was waited on immediately).
+// Mapping: lane = (column g = lane / LPC, disparity chunk k = lane % LPC), 16 disparities (8 packed registers) per lane,
+// CW = 64/LPC adjacent columns per wave, NWAVE waves per workgroup = one tile of TC = NWAVE*CW columns (2*SH2 of them
+// halo) that marches DOWN a band of rows:
+//   per row: (a) all threads stage the NEXT row's inputs into LDS: left records, and for the right image ready-made
+//                packed pair words W_q[r] = q[r] | q[r-1] << 16 for the six BT quantities (no byte shuffles later);
+//            (b) every lane evaluates the Birchfield-Tomasi cost of its 16 disparities (3 ds_read_b64 + 17 packed
+//                VALU per register) and slides the VERTICAL box sum, whose 2*SH2+1 rows live in registers;
+//            (c) vertical sums go to an LDS tile; one barrier; (d) each lane adds the 2*SH2+1 neighbouring columns
+//                (ds_read_b128) and streams C to HBM, 2 KB contiguous per wave.
+// Borders: columns clamp in cost coordinates, rows clamp to [clampTop, h-1] (replication, as the original).
+constexpr int COST2_NWAVE = 8;
+
+template <int LPC, int SH2>
+__global__ void __launch_bounds__(COST2_NWAVE * 64) k_cost2(const uint2 *__restrict__ recL, const uint2 *__restrict__ recR, SgmGeom g,
+                                                            int *__restrict__ cvol, int *__restrict__ cspec, int BAND, int nMain) {
+    constexpr int NPL = 8, CW = 64 / LPC, TC = COST2_NWAVE * CW, TO = TC - 2 * SH2, DP = 16 * LPC, DPW = NPL * LPC;
+    constexpr int R = 2 * SH2 + 1, NRR = TC + DP, NT = COST2_NWAVE * 64;
+    __shared__ int sW[2][NRR * 6];        // right-image pair words of one row, double buffered
+    __shared__ uint2 sL[2][TC];           // left records of one row
+    __shared__ int sV[2][TC * DPW];       // vertical box sums of the tile, double buffered
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, k = lane % LPC, grp = lane / LPC;
+    const int cl = w * CW + grp;                       // local column 0..TC-1
+    const int t0 = blockIdx.x * TO;                    // first OUTPUT cost column of the tile
+    const int xc = min(max(t0 - SH2 + cl, 0), g.W1 - 1);   // cost column this lane evaluates (replicated at the borders)
+    const int x = xc + g.minX1;                        // image column
+    const int r_base = max(t0 - SH2, 0) + g.minX1 - g.minD - (DP - 1);
+    const int ri0 = min(max(x - g.minD - 16 * k - r_base, 15), NRR - 1);   // pair-word index of this lane's lowest disparity
+    const size_t rowWords = (size_t)g.W1 * DPW;
+    int y0, y1, clampTop;
+    int *obase;
+    if ((int)blockIdx.y < nMain) {
+        y0 = blockIdx.y * BAND; y1 = min(y0 + BAND, g.H); clampTop = 0;
+        obase = cvol + (size_t)y0 * rowWords;
+    } else {
+        const int n = blockIdx.y - nMain + 1;
+        const int ss = max(min(n * g.stripe_sz - g.overlap, g.H), 0);
+        y0 = ss; y1 = min(ss + SH2, g.H); clampTop = ss;
+        obase = cspec + (size_t)(n - 1) * SH2 * rowWords;
+    }
+    if (y0 >= y1) return;
+    auto crow = [&](int yy) { return min(max(yy, clampTop), g.H - 1); };
+
+    // (a) staging of image row `row` into buffer b
+    auto stage = [&](int row, int b) {
+        const uint2 *lr = recL + (size_t)row * g.W, *rr = recR + (size_t)row * g.W;
+        if (tid < TC) {
+            const int xx = min(max(t0 - SH2 + tid, 0), g.W1 - 1) + g.minX1;
+            sL[b][tid] = lr[xx];
+        }
+        for (int ri = tid; ri < NRR; ri += NT) {
+            const int r = r_base + ri;
+            const uint2 A = rr[min(max(r, 0), g.W - 1)], B = rr[min(max(r - 1, 0), g.W - 1)];
+            int *o = &sW[b][ri * 6];
+            o[0] = __builtin_amdgcn_perm(B.x, A.x, 0x0c040c00); o[1] = __builtin_amdgcn_perm(B.x, A.x, 0x0c050c01);
+            o[2] = __builtin_amdgcn_perm(B.x, A.x, 0x0c060c02); o[3] = __builtin_amdgcn_perm(B.x, A.x, 0x0c070c03);
+            o[4] = __builtin_amdgcn_perm(B.y, A.y, 0x0c040c00); o[5] = __builtin_amdgcn_perm(B.y, A.y, 0x0c050c01);
+        }
+    };
+    // (b) BT pixel cost of this lane's 16 disparities from buffer b
+    auto pixel_cost = [&](int b, int (&pix)[NPL]) {
+        const uint2 lr = sL[b][cl];
+        const int Ug = __builtin_amdgcn_perm(lr.x, lr.x, 0x0c000c00), Ug0 = __builtin_amdgcn_perm(lr.x, lr.x, 0x0c010c01);
+        const int Ug1 = __builtin_amdgcn_perm(lr.x, lr.x, 0x0c020c02), Ui = __builtin_amdgcn_perm(lr.x, lr.x, 0x0c030c03);
+        const int Ui0 = __builtin_amdgcn_perm(lr.y, lr.y, 0x0c000c00), Ui1 = __builtin_amdgcn_perm(lr.y, lr.y, 0x0c010c01);
+#pragma unroll
+        for (int j = 0; j < NPL; j++) {
+            const int2 *p = (const int2 *)&sW[b][(ri0 - 2 * j) * 6];
+            const int2 a = p[0], bq = p[1], c = p[2];      // (Vg, Vg0) (Vg1, Vi) (Vi0, Vi1)
+            const int cg = bt_cost_pk(Ug, Ug0, Ug1, a.x, a.y, bq.x);
+            const int ci = bt_cost_pk(Ui, Ui0, Ui1, bq.y, c.x, c.y);
+            pix[j] = pk_add(cg, (ci >> 2) & 0x3fff3fff);
+        }
+    };
+
+    // The vertical window (R rows of pixel costs, each <= 189 so stored as bytes: 4 registers per row) lives in
+    // registers and is rotated by plain moves, which keeps the loop rolled and the register count predictable.
+    int ring[R][NPL / 2], vs[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; j++) vs[j] = 0;
+#pragma unroll
+    for (int q = 0; q < R; q++)
+#pragma unroll
+        for (int j = 0; j < NPL / 2; j++) ring[q][j] = 0;
+    const bool is_out = cl >= SH2 && cl < TC - SH2 && (t0 - SH2 + cl) < g.W1;
+    int *optr = obase + (size_t)(t0 - SH2 + cl) * DPW + k * NPL;
+    const int tile_x0 = t0 - SH2;
+    stage(crow(y0 - SH2), 0);
+    __syncthreads();
+    // iteration t: row e = y0 - SH2 + t enters the window (inputs in buffer t&1, staged one iteration earlier);
+    // from t = 2*SH2 on the window is full and output row y = e - SH2 is produced.  One barrier per iteration.
+    const int niter = (y1 - y0) + 2 * SH2;
+#pragma unroll 1
+    for (int t = 0; t < niter; t++) {
+        const int b = t & 1;
+        int pn[NPL];
+        pixel_cost(b, pn);
+#pragma unroll
+        for (int j = 0; j < NPL / 2; j++) {
+            const int old = ring[0][j];
+            vs[2 * j] = pk_add(pk_sub(vs[2 * j], __builtin_amdgcn_perm(old, old, 0x0c010c00)), pn[2 * j]);
+            vs[2 * j + 1] = pk_add(pk_sub(vs[2 * j + 1], __builtin_amdgcn_perm(old, old, 0x0c030c02)), pn[2 * j + 1]);
+        }
+#pragma unroll
+        for (int q = 0; q + 1 < R; q++)
+#pragma unroll
+            for (int j = 0; j < NPL / 2; j++) ring[q][j] = ring[q + 1][j];
+#pragma unroll
+        for (int j = 0; j < NPL / 2; j++) ring[R - 1][j] = __builtin_amdgcn_perm(pn[2 * j + 1], pn[2 * j], 0x06040200);
+        const bool outp = t >= 2 * SH2;
+        if (outp) {
+            *(int4 *)&sV[b][cl * DPW + k * NPL] = make_int4(vs[0], vs[1], vs[2], vs[3]);
+            *(int4 *)&sV[b][cl * DPW + k * NPL + 4] = make_int4(vs[4], vs[5], vs[6], vs[7]);
+        }
+        if (t + 1 < niter) stage(crow(y0 - SH2 + t + 1), b ^ 1);
+        __syncthreads();
+        if (outp && is_out) {
+            int c[NPL];
+#pragma unroll
+            for (int j = 0; j < NPL; j++) c[j] = 0;
+#pragma unroll
+            for (int i = -SH2; i <= SH2; i++) {
+                const int col = min(max(tile_x0 + cl + i, 0), g.W1 - 1) - tile_x0;
+                const int4 v0 = *(const int4 *)&sV[b][col * DPW + k * NPL], v1 = *(const int4 *)&sV[b][col * DPW + k * NPL + 4];
+                c[0] = pk_add(c[0], v0.x); c[1] = pk_add(c[1], v0.y); c[2] = pk_add(c[2], v0.z); c[3] = pk_add(c[3], v0.w);
+                c[4] = pk_add(c[4], v1.x); c[5] = pk_add(c[5], v1.y); c[6] = pk_add(c[6], v1.z); c[7] = pk_add(c[7], v1.w);
+            }
+            int *o = optr + (size_t)(t - 2 * SH2) * rowWords;
+            *(int4 *)o = make_int4(c[0], c[1], c[2], c[3]);
+            *(int4 *)(o + 4) = make_int4(c[4], c[5], c[6], c[7]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // k_hscan: one wave per image row: forward scan writes L_left, backward scan adds L_right in place.
 template <int NP, int U>
 __device__ __forceinline__ void load_run(int (&buf)[U][NP], const int *__restrict__ row, int x0, int dir, int W1, int NPW) {
@@ -880,6 +1016,44 @@ int derive_geom(r3d_ctx *ctx, const r3d_sgbm_params *p, int w, int h, SgmGeom &g
     return R3D_OK;
 }
 
+template <int LPC, int SH2>
+int launch_cost2_t(r3d_ctx *ctx, const SgmGeom &g, hipStream_t st) {
+    constexpr int CW = 64 / LPC, TC = COST2_NWAVE * CW, TO = TC - 2 * SH2;
+    static_assert(TO > 0, "tile too small for this block size");
+    const int tiles = (g.W1 + TO - 1) / TO;
+    // size the row bands so that one round of workgroups fills the chip (each band pays 2*SH2 extra rows of pixel cost)
+    int per_cu = 1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_cost2<LPC, SH2>, COST2_NWAVE * 64, 0);
+    if (per_cu < 1) per_cu = 1;
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const int slots = per_cu * cus;
+    int nb = slots / tiles;
+    if (nb < 1) nb = 1;
+    int BAND = (g.H + nb - 1) / nb;
+    if (BAND < 16) BAND = 16;
+    const int nMain = (g.H + BAND - 1) / BAND;
+    const int nSpec = SH2 > 0 ? 3 : 0;
+    k_cost2<LPC, SH2><<<dim3(tiles, nMain + nSpec), COST2_NWAVE * 64, 0, st>>>((const uint2 *)ctx->rec_l.p, (const uint2 *)ctx->rec_r.p, g,
+                                                                                 (int *)ctx->cost.p, (int *)ctx->cspec.p, BAND, nMain);
+    R3D_HIP(ctx, hipGetLastError());
+    return R3D_OK;
+}
+template <int LPC>
+int launch_cost2_l(r3d_ctx *ctx, const SgmGeom &g, hipStream_t st) {
+    switch (g.SH2) {
+        case 0: return launch_cost2_t<LPC, 0>(ctx, g, st);
+        case 1: return launch_cost2_t<LPC, 1>(ctx, g, st);
+        case 2: return launch_cost2_t<LPC, 2>(ctx, g, st);
+        case 3: return launch_cost2_t<LPC, 3>(ctx, g, st);
+        case 4: return launch_cost2_t<LPC, 4>(ctx, g, st);
+        default: return launch_cost2_t<LPC, 5>(ctx, g, st);
+    }
+}
+int launch_cost2(r3d_ctx *ctx, const SgmGeom &g, hipStream_t st) {
+    return g.NP == 1 ? launch_cost2_l<8>(ctx, g, st) : launch_cost2_l<16>(ctx, g, st);
+}
+
 }  // namespace
 
 int r3d_selftest_run(r3d_ctx *ctx) {
@@ -925,7 +1099,8 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
     k_prefilter<<<dim3((w + 255) / 256, h, 2), 256, 0, st>>>(d_left, d_right, stride, w, h, g.ftzero, (uint2 *)ctx->rec_l.p, (uint2 *)ctx->rec_r.p);
     R3D_HIP(ctx, hipGetLastError());
 
-    {
+    static const bool use_v1 = [] { const char *e = getenv("R3D_SGM_IMPL"); return e && !strcmp(e, "v1"); }();
+    if (use_v1) {
         r3d_prof_mark(ctx, "cost");
         const int TX = 16, BAND = 64;
         int RING = 8;
@@ -943,8 +1118,10 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
             k_cost<2><<<grid, COST_NW * 64, lds, st>>>((const uint2 *)ctx->rec_l.p, (const uint2 *)ctx->rec_r.p, g, (int *)ctx->cost.p, (int *)ctx->cspec.p, TX, BAND, nMain, RING);
         }
         R3D_HIP(ctx, hipGetLastError());
+    } else {
+        r3d_prof_mark(ctx, "cost");
+        if ((rc = launch_cost2(ctx, g, st))) return rc;
     }
-    static const bool use_v1 = [] { const char *e = getenv("R3D_SGM_IMPL"); return e && !strcmp(e, "v1"); }();
     r3d_prof_mark(ctx, "hscan");
     if (use_v1) {
         if (g.NP == 1) k_hscan<1><<<h, 64, 0, st>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, g);
