@@ -133,11 +133,13 @@ __device__ __forceinline__ int grp_allsum(int v) {
     return v;
 }
 
-// same recurrence as sgm_step, generic mapping; minp is uniform inside a group
-template <int NPL, int LPC>
+// same recurrence as sgm_step, generic mapping; minp is uniform inside a group.  Critical path per step:
+// add P2 -> pk_min -> pk_min -> pk_add -> (pk_min tree) -> sdwa min -> log2(LPC) butterfly stages.
+template <int NPL, int LPC, bool PADDED = true>
 __device__ __forceinline__ void sgm_step_g(int (&P)[NPL], int &minp, const int (&C)[NPL], int P1pk, int P2, bool first, bool last,
                                            bool lane_valid) {
-    const int mp2 = pk_dup(minp + P2);
+    const short m16 = (short)(minp + P2);
+    const int mp2 = as_i((s16x2){m16, m16});      // splat: folded into op_sel by the compiler
     const int up = grp_shr1<LPC>(P[NPL - 1], PADPK, first);
     const int dn = grp_shl1<LPC>(P[0], PADPK, last);
     int Q[NPL];
@@ -148,9 +150,10 @@ __device__ __forceinline__ void sgm_step_g(int (&P)[NPL], int &minp, const int (
         const int A = __builtin_amdgcn_alignbit(P[j], below, 16);
         const int B = __builtin_amdgcn_alignbit(above, P[j], 16);
         const int nb = pk_add_sat(pk_min(A, B), P1pk);
+        const int cm = pk_sub(C[j], mp2);                       // independent of the min chain
         const int m = pk_min(pk_min(P[j], mp2), nb);
-        const int q = pk_add(C[j], pk_sub(m, mp2));
-        Q[j] = lane_valid ? q : PADPK;
+        const int q = pk_add(cm, m);
+        Q[j] = (!PADDED || lane_valid) ? q : PADPK;
     }
     int m = Q[0];
 #pragma unroll
@@ -339,7 +342,11 @@ __global__ void __launch_bounds__(COST2_NWAVE * 64) k_cost2(const uint2 *__restr
                                                             int *__restrict__ cvol, int *__restrict__ cspec, int BAND, int nMain) {
     constexpr int NPL = 8, CW = 64 / LPC, TC = COST2_NWAVE * CW, TO = TC - 2 * SH2, DP = 16 * LPC, DPW = NPL * LPC;
     constexpr int R = 2 * SH2 + 1, NRR = TC + DP, NT = COST2_NWAVE * 64;
-    __shared__ int sW[2][NRR * 6];        // right-image pair words of one row, double buffered
+    // pair words: 6 dwords per right pixel, plus 8 dwords of padding after every 16 pixels: lanes of one column group
+    // read records 16 apart (16*6 dwords = 32 mod 64 banks -> 4-way conflicts); with the pad the eight chunks land on
+    // eight different multiples of 8 banks and the four column groups of a half-wave fill the gaps: conflict-free.
+    constexpr int SWN = NRR * 6 + (NRR / 16 + 1) * 8;
+    __shared__ int sW[2][SWN];            // right-image pair words of one row, double buffered
     __shared__ uint2 sL[2][TC];           // left records of one row
     __shared__ int sV[2][TC * DPW];       // vertical box sums of the tile, double buffered
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, k = lane % LPC, grp = lane / LPC;
@@ -374,7 +381,7 @@ __global__ void __launch_bounds__(COST2_NWAVE * 64) k_cost2(const uint2 *__restr
         for (int ri = tid; ri < NRR; ri += NT) {
             const int r = r_base + ri;
             const uint2 A = rr[min(max(r, 0), g.W - 1)], B = rr[min(max(r - 1, 0), g.W - 1)];
-            int *o = &sW[b][ri * 6];
+            int *o = &sW[b][ri * 6 + (ri >> 4) * 8];
             o[0] = __builtin_amdgcn_perm(B.x, A.x, 0x0c040c00); o[1] = __builtin_amdgcn_perm(B.x, A.x, 0x0c050c01);
             o[2] = __builtin_amdgcn_perm(B.x, A.x, 0x0c060c02); o[3] = __builtin_amdgcn_perm(B.x, A.x, 0x0c070c03);
             o[4] = __builtin_amdgcn_perm(B.y, A.y, 0x0c040c00); o[5] = __builtin_amdgcn_perm(B.y, A.y, 0x0c050c01);
@@ -388,7 +395,8 @@ __global__ void __launch_bounds__(COST2_NWAVE * 64) k_cost2(const uint2 *__restr
         const int Ui0 = __builtin_amdgcn_perm(lr.y, lr.y, 0x0c000c00), Ui1 = __builtin_amdgcn_perm(lr.y, lr.y, 0x0c010c01);
 #pragma unroll
         for (int j = 0; j < NPL; j++) {
-            const int2 *p = (const int2 *)&sW[b][(ri0 - 2 * j) * 6];
+            const int rj = ri0 - 2 * j;
+            const int2 *p = (const int2 *)&sW[b][rj * 6 + (rj >> 4) * 8];
             const int2 a = p[0], bq = p[1], c = p[2];      // (Vg, Vg0) (Vg1, Vi) (Vi0, Vi1)
             const int cg = bt_cost_pk(Ug, Ug0, Ug1, a.x, a.y, bq.x);
             const int ci = bt_cost_pk(Ui, Ui0, Ui1, bq.y, c.x, c.y);
@@ -432,8 +440,10 @@ __global__ void __launch_bounds__(COST2_NWAVE * 64) k_cost2(const uint2 *__restr
         for (int j = 0; j < NPL / 2; j++) ring[R - 1][j] = __builtin_amdgcn_perm(pn[2 * j + 1], pn[2 * j], 0x06040200);
         const bool outp = t >= 2 * SH2;
         if (outp) {
-            *(int4 *)&sV[b][cl * DPW + k * NPL] = make_int4(vs[0], vs[1], vs[2], vs[3]);
-            *(int4 *)&sV[b][cl * DPW + k * NPL + 4] = make_int4(vs[4], vs[5], vs[6], vs[7]);
+            // tile layout: column-major, inside a column the two 16-byte halves of all lanes are stored as two planes
+            // whose order alternates with the column parity: conflict-free for the b128 write and the b128 reads below
+            *(int4 *)&sV[b][cl * DPW + (DPW / 2) * (cl & 1) + 4 * k] = make_int4(vs[0], vs[1], vs[2], vs[3]);
+            *(int4 *)&sV[b][cl * DPW + (DPW / 2) * ((cl & 1) ^ 1) + 4 * k] = make_int4(vs[4], vs[5], vs[6], vs[7]);
         }
         if (t + 1 < niter) stage(crow(y0 - SH2 + t + 1), b ^ 1);
         __syncthreads();
@@ -444,7 +454,8 @@ __global__ void __launch_bounds__(COST2_NWAVE * 64) k_cost2(const uint2 *__restr
 #pragma unroll
             for (int i = -SH2; i <= SH2; i++) {
                 const int col = min(max(tile_x0 + cl + i, 0), g.W1 - 1) - tile_x0;
-                const int4 v0 = *(const int4 *)&sV[b][col * DPW + k * NPL], v1 = *(const int4 *)&sV[b][col * DPW + k * NPL + 4];
+                const int4 v0 = *(const int4 *)&sV[b][col * DPW + (DPW / 2) * (col & 1) + 4 * k];
+                const int4 v1 = *(const int4 *)&sV[b][col * DPW + (DPW / 2) * ((col & 1) ^ 1) + 4 * k];
                 c[0] = pk_add(c[0], v0.x); c[1] = pk_add(c[1], v0.y); c[2] = pk_add(c[2], v0.z); c[3] = pk_add(c[3], v0.w);
                 c[4] = pk_add(c[4], v1.x); c[5] = pk_add(c[5], v1.y); c[6] = pk_add(c[6], v1.z); c[7] = pk_add(c[7], v1.w);
             }
@@ -643,7 +654,7 @@ __global__ void __launch_bounds__(64) k_vscan(const int *__restrict__ cvol, cons
 //            runs over the same registers and streams L_left + L_right to HBM.
 // HBM traffic per row: C read twice, sum written once, + 2 * 8 B * 64 * W1/K of checkpoints (6 % at K = 32).
 // A tail of W1 % K columns uses the v1 scheme (L_left parked in the output row).
-template <int NP, int K>
+template <int NP, int K, bool PADDED>
 __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int *__restrict__ hvol, int *__restrict__ ckpt, SgmGeom g) {
     constexpr int NPW = NP * 64, CKW = (NP + 1) * 64;
     const int lane = threadIdx.x, y = blockIdx.x;
@@ -653,7 +664,7 @@ __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int
     int *ck = ckpt + (size_t)y * (nfull + 1) * CKW + lane * (NP + 1);
     const bool valid = 2 * NP * lane < g.D, first = lane == 0, last = lane == 63;
     int P[NP], minp = 0;
-    int cA[K][NP], cB[K][NP], ll[K][NP];
+    int cX[K][NP], cY[K][NP], cZ[K][NP], llA[K][NP], llB[K][NP];
 #pragma unroll
     for (int j = 0; j < NP; j++) P[j] = valid ? 0 : PADPK;
     auto load_seg = [&](int (&buf)[K][NP], int sidx) {
@@ -669,19 +680,24 @@ __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int
         for (int j = 0; j < NP; j++) ck[(size_t)sidx * CKW + j] = P[j];
         ck[(size_t)sidx * CKW + NP] = minp;
     };
-    // ---- phase 1
+    auto load_ck = [&](int sidx) {
+#pragma unroll
+        for (int j = 0; j < NP; j++) P[j] = ck[(size_t)sidx * CKW + j];
+        minp = ck[(size_t)sidx * CKW + NP];
+    };
+    // ---- phase 1: forward chain, checkpoint the state entering every segment
     if (nfull > 0) {
-        load_seg(cA, 0);
+        load_seg(cX, 0);
         for (int s0 = 0; s0 < nfull; s0 += 2) {
-            load_seg(cB, s0 + 1);
+            load_seg(cY, s0 + 1);
             save_ck(s0);
 #pragma unroll
-            for (int u = 0; u < K; u++) sgm_step_g<NP, 64>(P, minp, cA[u], P1pk, g.P2, first, last, valid);
+            for (int u = 0; u < K; u++) sgm_step_g<NP, 64, PADDED>(P, minp, cX[u], P1pk, g.P2, first, last, valid);
             if (s0 + 1 < nfull) {
-                load_seg(cA, s0 + 2);
+                load_seg(cX, s0 + 2);
                 save_ck(s0 + 1);
 #pragma unroll
-                for (int u = 0; u < K; u++) sgm_step_g<NP, 64>(P, minp, cB[u], P1pk, g.P2, first, last, valid);
+                for (int u = 0; u < K; u++) sgm_step_g<NP, 64, PADDED>(P, minp, cY[u], P1pk, g.P2, first, last, valid);
             }
         }
     }
@@ -690,11 +706,12 @@ __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int
         int c[NP];
 #pragma unroll
         for (int j = 0; j < NP; j++) c[j] = crow[(size_t)x * NPW + j];
-        sgm_step_g<NP, 64>(P, minp, c, P1pk, g.P2, first, last, valid);
+        sgm_step_g<NP, 64, PADDED>(P, minp, c, P1pk, g.P2, first, last, valid);
 #pragma unroll
         for (int j = 0; j < NP; j++) hrow[(size_t)x * NPW + j] = P[j];
     }
-    // ---- phase 2
+    // ---- phase 2: backward chain; the forward chain of the NEXT (left) segment is recomputed in the same instruction
+    // stream, so two independent dependency chains are in flight per wave
     int R[NP], minr = 0;
 #pragma unroll
     for (int j = 0; j < NP; j++) R[j] = valid ? 0 : PADPK;
@@ -702,37 +719,48 @@ __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int
         int c[NP];
 #pragma unroll
         for (int j = 0; j < NP; j++) c[j] = crow[(size_t)x * NPW + j];
-        sgm_step_g<NP, 64>(R, minr, c, P1pk, g.P2, first, last, valid);
+        sgm_step_g<NP, 64, PADDED>(R, minr, c, P1pk, g.P2, first, last, valid);
 #pragma unroll
         for (int j = 0; j < NP; j++) hrow[(size_t)x * NPW + j] = pk_add(hrow[(size_t)x * NPW + j], R[j]);
     }
-    auto run_seg = [&](int (&cb)[K][NP], int sidx) {
-#pragma unroll
-        for (int j = 0; j < NP; j++) P[j] = ck[(size_t)sidx * CKW + j];
-        minp = ck[(size_t)sidx * CKW + NP];
+    if (nfull > 0) {
+        load_seg(cX, nfull - 1);
+        load_seg(cY, nfull - 2);
+        load_ck(nfull - 1);
 #pragma unroll
         for (int u = 0; u < K; u++) {
-            sgm_step_g<NP, 64>(P, minp, cb[u], P1pk, g.P2, first, last, valid);
+            sgm_step_g<NP, 64, PADDED>(P, minp, cX[u], P1pk, g.P2, first, last, valid);
 #pragma unroll
-            for (int j = 0; j < NP; j++) ll[u][j] = P[j];
+            for (int j = 0; j < NP; j++) llA[u][j] = P[j];
         }
-        int *hp = hrow + (size_t)sidx * K * NPW;
+#pragma unroll 1
+        for (int s = nfull - 1; s >= 0; s--) {
+            // cX / llA: segment s (costs, L_left);  cY: segment s-1;  cZ <- segment s-2 (prefetch)
+            load_seg(cZ, s - 2);
+            int *hp = hrow + (size_t)s * K * NPW;
+            if (s > 0) {
+                load_ck(s - 1);
 #pragma unroll
-        for (int u = K - 1; u >= 0; u--) {
-            sgm_step_g<NP, 64>(R, minr, cb[u], P1pk, g.P2, first, last, valid);
+                for (int u = 0; u < K; u++) {
+                    sgm_step_g<NP, 64, PADDED>(R, minr, cX[K - 1 - u], P1pk, g.P2, first, last, valid);
 #pragma unroll
-            for (int j = 0; j < NP; j++) hp[(size_t)u * NPW + j] = pk_add(ll[u][j], R[j]);
-        }
-    };
-    if (nfull > 0) {
-        load_seg(cA, nfull - 1);
-        for (int s0 = nfull - 1; s0 >= 0; s0 -= 2) {
-            load_seg(cB, s0 - 1);
-            run_seg(cA, s0);
-            if (s0 - 1 >= 0) {
-                load_seg(cA, s0 - 2);
-                run_seg(cB, s0 - 1);
+                    for (int j = 0; j < NP; j++) hp[(size_t)(K - 1 - u) * NPW + j] = pk_add(llA[K - 1 - u][j], R[j]);
+                    sgm_step_g<NP, 64, PADDED>(P, minp, cY[u], P1pk, g.P2, first, last, valid);
+#pragma unroll
+                    for (int j = 0; j < NP; j++) llB[u][j] = P[j];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < K; u++) {
+                    sgm_step_g<NP, 64, PADDED>(R, minr, cX[K - 1 - u], P1pk, g.P2, first, last, valid);
+#pragma unroll
+                    for (int j = 0; j < NP; j++) hp[(size_t)(K - 1 - u) * NPW + j] = pk_add(llA[K - 1 - u][j], R[j]);
+                }
             }
+#pragma unroll
+            for (int u = 0; u < K; u++)
+#pragma unroll
+                for (int j = 0; j < NP; j++) { cX[u][j] = cY[u][j]; cY[u][j] = cZ[u][j]; llA[u][j] = llB[u][j]; }
         }
     }
 }
@@ -1127,11 +1155,19 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
         if (g.NP == 1) k_hscan<1><<<h, 64, 0, st>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, g);
         else k_hscan<2><<<h, 64, 0, st>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, g);
     } else {
-        constexpr int K1 = 32, K2 = 16;
+        constexpr int K1 = 16, K2 = 8;
         const int K = g.NP == 1 ? K1 : K2;
+        const bool padded = g.D != 128 * g.NP;
         if ((rc = r3d_reserve(ctx, ctx->ckpt, (size_t)h * (g.W1 / K + 1) * (g.NP + 1) * 64 * 4))) return rc;
-        if (g.NP == 1) k_hscan2<1, K1><<<h, 64, 0, st>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, (int *)ctx->ckpt.p, g);
-        else k_hscan2<2, K2><<<h, 64, 0, st>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, (int *)ctx->ckpt.p, g);
+        const int *cp = (const int *)ctx->cost.p;
+        int *hp = (int *)ctx->hsum.p, *kp = (int *)ctx->ckpt.p;
+        if (g.NP == 1) {
+            if (padded) k_hscan2<1, K1, true><<<h, 64, 0, st>>>(cp, hp, kp, g);
+            else k_hscan2<1, K1, false><<<h, 64, 0, st>>>(cp, hp, kp, g);
+        } else {
+            if (padded) k_hscan2<2, K2, true><<<h, 64, 0, st>>>(cp, hp, kp, g);
+            else k_hscan2<2, K2, false><<<h, 64, 0, st>>>(cp, hp, kp, g);
+        }
     }
     R3D_HIP(ctx, hipGetLastError());
 
