@@ -163,6 +163,38 @@ __device__ __forceinline__ void sgm_step_g(int (&P)[NPL], int &minp, const int (
     minp = grp_allmin<LPC>(min(lo16(m), hi16(m)));
 }
 
+// Two independent chains (A, B) of the wave-wide mapping (NPL = 1, LPC = 64) advanced in lockstep: their per-lane minima
+// travel through ONE packed butterfly (lo16 = A, hi16 = B; v_pk_min_i16 cannot take a DPP modifier, so each of the
+// four row stages is mov_dpp + pk_min), which both shortens the instruction stream and hard-wires the interleave that
+// the scheduler does not find by itself.  minAB holds (min A | min B << 16).
+__device__ __forceinline__ int pk_allmin64(int v) {
+    // every lane has a source in these four permutations, so the DPP move needs no `old` value (no extra copy)
+    v = pk_min(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true));
+    v = pk_min(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true));
+    v = pk_min(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true));
+    v = pk_min(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true));
+    { auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); v = pk_min((int)r[0], (int)r[1]); }
+    { auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false); v = pk_min((int)r[0], (int)r[1]); }
+    return v;
+}
+template <bool PADDED>
+__device__ __forceinline__ void sgm_step_dual(int &PA, int &PB, int &minAB, int CA, int CB, int P1pk, int P2pk, bool lane_valid) {
+    const s16x2 m = as_s(pk_add(minAB, P2pk));
+    const int mp2A = as_i((s16x2){m.x, m.x}), mp2B = as_i((s16x2){m.y, m.y});
+    const int upA = wave_shr1(PA, PADPK), upB = wave_shr1(PB, PADPK);
+    const int dnA = wave_shl1(PA, PADPK), dnB = wave_shl1(PB, PADPK);
+    const int nbA = pk_add_sat(pk_min(__builtin_amdgcn_alignbit(PA, upA, 16), __builtin_amdgcn_alignbit(dnA, PA, 16)), P1pk);
+    const int nbB = pk_add_sat(pk_min(__builtin_amdgcn_alignbit(PB, upB, 16), __builtin_amdgcn_alignbit(dnB, PB, 16)), P1pk);
+    const int cmA = pk_sub(CA, mp2A), cmB = pk_sub(CB, mp2B);
+    int qA = pk_add(cmA, pk_min(pk_min(PA, mp2A), nbA));
+    int qB = pk_add(cmB, pk_min(pk_min(PB, mp2B), nbB));
+    if (PADDED) { qA = lane_valid ? qA : PADPK; qB = lane_valid ? qB : PADPK; }
+    PA = qA; PB = qB;
+    // (lo A | lo B << 16) vs (hi A | hi B << 16)
+    const int lo = __builtin_amdgcn_perm(qB, qA, 0x05040100), hi = __builtin_amdgcn_perm(qB, qA, 0x07060302);
+    minAB = pk_allmin64(pk_min(lo, hi));
+}
+
 // trunc(n / d) for d > 0, |n|, d < 2^23: float reciprocal estimate + exact integer correction
 __device__ __forceinline__ int trunc_div_small(int n, int d) {
     int q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
@@ -740,14 +772,27 @@ __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int
             int *hp = hrow + (size_t)s * K * NPW;
             if (s > 0) {
                 load_ck(s - 1);
+                if constexpr (NP == 1) {
+                    int mAB = (minr & 0xffff) | (minp << 16);
+                    const int P2pk = pk_dup(g.P2);
 #pragma unroll
-                for (int u = 0; u < K; u++) {
-                    sgm_step_g<NP, 64, PADDED>(R, minr, cX[K - 1 - u], P1pk, g.P2, first, last, valid);
+                    for (int u = 0; u < K; u++) {
+                        sgm_step_dual<PADDED>(R[0], P[0], mAB, cX[K - 1 - u][0], cY[u][0], P1pk, P2pk, valid);
+                        hp[(size_t)(K - 1 - u) * NPW] = pk_add(llA[K - 1 - u][0], R[0]);
+                        llB[u][0] = P[0];
+                    }
+                    minr = lo16(mAB);
+                    minp = hi16(mAB);
+                } else {
 #pragma unroll
-                    for (int j = 0; j < NP; j++) hp[(size_t)(K - 1 - u) * NPW + j] = pk_add(llA[K - 1 - u][j], R[j]);
-                    sgm_step_g<NP, 64, PADDED>(P, minp, cY[u], P1pk, g.P2, first, last, valid);
+                    for (int u = 0; u < K; u++) {
+                        sgm_step_g<NP, 64, PADDED>(R, minr, cX[K - 1 - u], P1pk, g.P2, first, last, valid);
 #pragma unroll
-                    for (int j = 0; j < NP; j++) llB[u][j] = P[j];
+                        for (int j = 0; j < NP; j++) hp[(size_t)(K - 1 - u) * NPW + j] = pk_add(llA[K - 1 - u][j], R[j]);
+                        sgm_step_g<NP, 64, PADDED>(P, minp, cY[u], P1pk, g.P2, first, last, valid);
+#pragma unroll
+                        for (int j = 0; j < NP; j++) llB[u][j] = P[j];
+                    }
                 }
             } else {
 #pragma unroll
@@ -977,6 +1022,19 @@ __global__ void __launch_bounds__(64) k_selftest(int *out) {
         if (lo16(P[0]) != want[0] || hi16(P[0]) != want[1]) bad |= 1024;
         int wm = wave_allmin_i32(min(want[0], want[1]));
         if (minp != wm) bad |= 2048;
+    }
+    // dual-chain step == two single steps
+    {
+        int PA[1] = {(((lane * 7) % 13) & 0xffff) | ((((lane * 5) % 11)) << 16)}, PB[1] = {(((lane * 3) % 17) & 0xffff) | ((((lane * 11) % 7)) << 16)};
+        int mA = wave_allmin_i32(min(lo16(PA[0]), hi16(PA[0]))), mB = wave_allmin_i32(min(lo16(PB[0]), hi16(PB[0])));
+        const int CA[1] = {((lane + 3) & 0xffff) | ((2 * lane + 1) << 16)}, CB[1] = {((5 * lane + 2) & 0xffff) | ((lane + 9) << 16)};
+        int dA = PA[0], dB = PB[0], mAB = (mA & 0xffff) | (mB << 16);
+        for (int it = 0; it < 3; it++) {
+            sgm_step_g<1, 64, false>(PA, mA, CA, pk_dup(3), 9, lane == 0, lane == 63, true);
+            sgm_step_g<1, 64, false>(PB, mB, CB, pk_dup(3), 9, lane == 0, lane == 63, true);
+            sgm_step_dual<false>(dA, dB, mAB, CA[0], CB[0], pk_dup(3), pk_dup(9), true);
+            if (dA != PA[0] || dB != PB[0] || lo16(mAB) != mA || hi16(mAB) != mB) bad |= 1 << 23;
+        }
     }
     // generic group helpers (v2 kernels), LPC = 8 and 16
     {
