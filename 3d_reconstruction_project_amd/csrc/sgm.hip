@@ -692,11 +692,13 @@ __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int
     const int lane = threadIdx.x, y = blockIdx.x;
     const int *crow = cvol + (size_t)y * g.W1 * NPW + lane * NP;
     int *hrow = hvol + (size_t)y * g.W1 * NPW + lane * NP;
-    const int W1 = g.W1, nfull = W1 / K, P1pk = pk_dup(g.P1);
+    const int W1 = g.W1, nfull = W1 / K, P1pk = pk_dup(g.P1), P2pk = pk_dup(g.P2);
     int *ck = ckpt + (size_t)y * (nfull + 1) * CKW + lane * (NP + 1);
     const bool valid = 2 * NP * lane < g.D, first = lane == 0, last = lane == 63;
     int P[NP], minp = 0;
-    int cX[K][NP], cY[K][NP], cZ[K][NP], llA[K][NP], llB[K][NP];
+    // four rotating cost buffers: a segment is requested two rounds (2*K steps) before its first use and is never
+    // touched in between, so the loads stay in flight across whole rounds
+    int c0[K][NP], c1[K][NP], c2[K][NP], c3[K][NP], llA[K][NP], llB[K][NP];
 #pragma unroll
     for (int j = 0; j < NP; j++) P[j] = valid ? 0 : PADPK;
     auto load_seg = [&](int (&buf)[K][NP], int sidx) {
@@ -718,19 +720,20 @@ __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int
         minp = ck[(size_t)sidx * CKW + NP];
     };
     // ---- phase 1: forward chain, checkpoint the state entering every segment
+    auto fwd_round = [&](int (&cur)[K][NP], int (&pre)[K][NP], int sidx) {   // pre <- segment sidx+3
+        load_seg(pre, sidx + 3);
+        save_ck(sidx);
+#pragma unroll
+        for (int u = 0; u < K; u++) sgm_step_g<NP, 64, PADDED>(P, minp, cur[u], P1pk, g.P2, first, last, valid);
+    };
     if (nfull > 0) {
-        load_seg(cX, 0);
-        for (int s0 = 0; s0 < nfull; s0 += 2) {
-            load_seg(cY, s0 + 1);
-            save_ck(s0);
-#pragma unroll
-            for (int u = 0; u < K; u++) sgm_step_g<NP, 64, PADDED>(P, minp, cX[u], P1pk, g.P2, first, last, valid);
-            if (s0 + 1 < nfull) {
-                load_seg(cX, s0 + 2);
-                save_ck(s0 + 1);
-#pragma unroll
-                for (int u = 0; u < K; u++) sgm_step_g<NP, 64, PADDED>(P, minp, cY[u], P1pk, g.P2, first, last, valid);
-            }
+        load_seg(c0, 0); load_seg(c1, 1); load_seg(c2, 2);
+#pragma unroll 1
+        for (int s0 = 0; s0 < nfull; s0 += 4) {
+            fwd_round(c0, c3, s0);
+            if (s0 + 1 < nfull) fwd_round(c1, c0, s0 + 1);
+            if (s0 + 2 < nfull) fwd_round(c2, c1, s0 + 2);
+            if (s0 + 3 < nfull) fwd_round(c3, c2, s0 + 3);
         }
     }
     // tail columns [nfull*K, W1): forward values parked in the output row
@@ -742,8 +745,7 @@ __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int
 #pragma unroll
         for (int j = 0; j < NP; j++) hrow[(size_t)x * NPW + j] = P[j];
     }
-    // ---- phase 2: backward chain; the forward chain of the NEXT (left) segment is recomputed in the same instruction
-    // stream, so two independent dependency chains are in flight per wave
+    // ---- phase 2: backward chain of segment s in lockstep with the recomputed forward chain of segment s-1
     int R[NP], minr = 0;
 #pragma unroll
     for (int j = 0; j < NP; j++) R[j] = valid ? 0 : PADPK;
@@ -755,57 +757,61 @@ __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int
 #pragma unroll
         for (int j = 0; j < NP; j++) hrow[(size_t)x * NPW + j] = pk_add(hrow[(size_t)x * NPW + j], R[j]);
     }
+    // round(s): A = costs of segment s (backward), B = costs of segment s-1 (forward), pre <- segment s-3
+    auto bwd_round = [&](int (&A)[K][NP], int (&B)[K][NP], int (&pre)[K][NP], int sidx) {
+        load_seg(pre, sidx - 3);
+        int *hp = hrow + (size_t)sidx * K * NPW;
+        if (sidx > 0) {
+            load_ck(sidx - 1);
+            if constexpr (NP == 1) {
+                int mAB = (minr & 0xffff) | (minp << 16);
+#pragma unroll
+                for (int u = 0; u < K; u++) {
+                    sgm_step_dual<PADDED>(R[0], P[0], mAB, A[K - 1 - u][0], B[u][0], P1pk, P2pk, valid);
+                    hp[(size_t)(K - 1 - u) * NPW] = pk_add(llA[K - 1 - u][0], R[0]);
+                    llB[u][0] = P[0];
+                }
+                minr = lo16(mAB);
+                minp = hi16(mAB);
+            } else {
+#pragma unroll
+                for (int u = 0; u < K; u++) {
+                    sgm_step_g<NP, 64, PADDED>(R, minr, A[K - 1 - u], P1pk, g.P2, first, last, valid);
+#pragma unroll
+                    for (int j = 0; j < NP; j++) hp[(size_t)(K - 1 - u) * NPW + j] = pk_add(llA[K - 1 - u][j], R[j]);
+                    sgm_step_g<NP, 64, PADDED>(P, minp, B[u], P1pk, g.P2, first, last, valid);
+#pragma unroll
+                    for (int j = 0; j < NP; j++) llB[u][j] = P[j];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < K; u++) {
+                sgm_step_g<NP, 64, PADDED>(R, minr, A[K - 1 - u], P1pk, g.P2, first, last, valid);
+#pragma unroll
+                for (int j = 0; j < NP; j++) hp[(size_t)(K - 1 - u) * NPW + j] = pk_add(llA[K - 1 - u][j], R[j]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < K; u++)
+#pragma unroll
+            for (int j = 0; j < NP; j++) llA[u][j] = llB[u][j];
+    };
     if (nfull > 0) {
-        load_seg(cX, nfull - 1);
-        load_seg(cY, nfull - 2);
+        load_seg(c0, nfull - 1); load_seg(c1, nfull - 2); load_seg(c2, nfull - 3);
         load_ck(nfull - 1);
 #pragma unroll
         for (int u = 0; u < K; u++) {
-            sgm_step_g<NP, 64, PADDED>(P, minp, cX[u], P1pk, g.P2, first, last, valid);
+            sgm_step_g<NP, 64, PADDED>(P, minp, c0[u], P1pk, g.P2, first, last, valid);
 #pragma unroll
             for (int j = 0; j < NP; j++) llA[u][j] = P[j];
         }
 #pragma unroll 1
-        for (int s = nfull - 1; s >= 0; s--) {
-            // cX / llA: segment s (costs, L_left);  cY: segment s-1;  cZ <- segment s-2 (prefetch)
-            load_seg(cZ, s - 2);
-            int *hp = hrow + (size_t)s * K * NPW;
-            if (s > 0) {
-                load_ck(s - 1);
-                if constexpr (NP == 1) {
-                    int mAB = (minr & 0xffff) | (minp << 16);
-                    const int P2pk = pk_dup(g.P2);
-#pragma unroll
-                    for (int u = 0; u < K; u++) {
-                        sgm_step_dual<PADDED>(R[0], P[0], mAB, cX[K - 1 - u][0], cY[u][0], P1pk, P2pk, valid);
-                        hp[(size_t)(K - 1 - u) * NPW] = pk_add(llA[K - 1 - u][0], R[0]);
-                        llB[u][0] = P[0];
-                    }
-                    minr = lo16(mAB);
-                    minp = hi16(mAB);
-                } else {
-#pragma unroll
-                    for (int u = 0; u < K; u++) {
-                        sgm_step_g<NP, 64, PADDED>(R, minr, cX[K - 1 - u], P1pk, g.P2, first, last, valid);
-#pragma unroll
-                        for (int j = 0; j < NP; j++) hp[(size_t)(K - 1 - u) * NPW + j] = pk_add(llA[K - 1 - u][j], R[j]);
-                        sgm_step_g<NP, 64, PADDED>(P, minp, cY[u], P1pk, g.P2, first, last, valid);
-#pragma unroll
-                        for (int j = 0; j < NP; j++) llB[u][j] = P[j];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < K; u++) {
-                    sgm_step_g<NP, 64, PADDED>(R, minr, cX[K - 1 - u], P1pk, g.P2, first, last, valid);
-#pragma unroll
-                    for (int j = 0; j < NP; j++) hp[(size_t)(K - 1 - u) * NPW + j] = pk_add(llA[K - 1 - u][j], R[j]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < K; u++)
-#pragma unroll
-                for (int j = 0; j < NP; j++) { cX[u][j] = cY[u][j]; cY[u][j] = cZ[u][j]; llA[u][j] = llB[u][j]; }
+        for (int s = nfull - 1; s >= 0; s -= 4) {
+            bwd_round(c0, c1, c3, s);
+            if (s - 1 >= 0) bwd_round(c1, c2, c0, s - 1);
+            if (s - 2 >= 0) bwd_round(c2, c3, c1, s - 2);
+            if (s - 3 >= 0) bwd_round(c3, c0, c2, s - 3);
         }
     }
 }
