@@ -41,6 +41,7 @@ _SIGS = {
     "r3d_set_stream": ([_vp, _vp], ctypes.c_int),
     "r3d_get_stream": ([_vp], _vp),
     "r3d_selftest": ([_vp], ctypes.c_int),
+    "r3d_debug_streambench": ([_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)], ctypes.c_int),
     "r3d_dev_alloc": ([_vp, ctypes.c_uint64, ctypes.POINTER(_vp)], ctypes.c_int),
     "r3d_dev_free": ([_vp, _vp], ctypes.c_int),
     "r3d_copy_h2d": ([_vp, _vp, _vp, ctypes.c_uint64], ctypes.c_int),

@@ -115,6 +115,11 @@ int r3d_set_stream(r3d_ctx *ctx, void *s) {
 }
 void *r3d_get_stream(r3d_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+int r3d_debug_streambench(r3d_ctx *ctx, int32_t mode, int32_t rows, uint64_t row_bytes, int32_t write, int32_t delay, int32_t reps, float *ms) {
+    if (!ctx || !ms || rows <= 0 || reps <= 0) return R3D_E_BADARG;
+    return r3d_streambench_run(ctx, mode, rows, row_bytes, write, delay, reps, ms);
+}
+
 int r3d_selftest(r3d_ctx *ctx) {
     if (!ctx) return R3D_E_BADARG;
     return r3d_selftest_run(ctx);

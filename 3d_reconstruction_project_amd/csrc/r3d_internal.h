@@ -89,3 +89,4 @@ static inline void r3d_prof_end(r3d_ctx *ctx) {
 int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, const uint8_t *d_right, int w, int h,
                 int stride, int16_t *d_disp);
 int r3d_selftest_run(r3d_ctx *ctx);
+int r3d_streambench_run(r3d_ctx *ctx, int mode, int rows, size_t row_bytes, int write, int delay, int reps, float *ms);

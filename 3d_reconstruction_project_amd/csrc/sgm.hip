@@ -195,6 +195,46 @@ __device__ __forceinline__ void sgm_step_dual(int &PA, int &PB, int &minAB, int 
     minAB = pk_allmin64(pk_min(lo, hi));
 }
 
+// packed (two int16 lanes) all-reduce min inside each LPC-lane group
+template <int LPC>
+__device__ __forceinline__ int pk_grp_allmin(int v) {
+    if constexpr (LPC >= 2) v = pk_min(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true));
+    if constexpr (LPC >= 4) v = pk_min(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true));
+    if constexpr (LPC >= 8) v = pk_min(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true));
+    if constexpr (LPC >= 16) v = pk_min(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true));
+    if constexpr (LPC >= 32) { auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); v = pk_min((int)r[0], (int)r[1]); }
+    if constexpr (LPC >= 64) { auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false); v = pk_min((int)r[0], (int)r[1]); }
+    return v;
+}
+// two independent chains (A, B) of the generic mapping advanced in lockstep, sharing one packed butterfly
+template <int NPL, int LPC, bool PADDED>
+__device__ __forceinline__ void sgm_step_dual_g(int (&PA)[NPL], int (&PB)[NPL], int &minAB, const int (&CA)[NPL], const int (&CB)[NPL],
+                                                int P1pk, int P2pk, bool first, bool last, bool lane_valid) {
+    const s16x2 m = as_s(pk_add(minAB, P2pk));
+    const int mp2A = as_i((s16x2){m.x, m.x}), mp2B = as_i((s16x2){m.y, m.y});
+    const int upA = grp_shr1<LPC>(PA[NPL - 1], PADPK, first), upB = grp_shr1<LPC>(PB[NPL - 1], PADPK, first);
+    const int dnA = grp_shl1<LPC>(PA[0], PADPK, last), dnB = grp_shl1<LPC>(PB[0], PADPK, last);
+    int QA[NPL], QB[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        const int belowA = j == 0 ? upA : PA[j - 1], aboveA = j == NPL - 1 ? dnA : PA[j + 1];
+        const int belowB = j == 0 ? upB : PB[j - 1], aboveB = j == NPL - 1 ? dnB : PB[j + 1];
+        const int nbA = pk_add_sat(pk_min(__builtin_amdgcn_alignbit(PA[j], belowA, 16), __builtin_amdgcn_alignbit(aboveA, PA[j], 16)), P1pk);
+        const int nbB = pk_add_sat(pk_min(__builtin_amdgcn_alignbit(PB[j], belowB, 16), __builtin_amdgcn_alignbit(aboveB, PB[j], 16)), P1pk);
+        int qA = pk_add(pk_sub(CA[j], mp2A), pk_min(pk_min(PA[j], mp2A), nbA));
+        int qB = pk_add(pk_sub(CB[j], mp2B), pk_min(pk_min(PB[j], mp2B), nbB));
+        if (PADDED) { qA = lane_valid ? qA : PADPK; qB = lane_valid ? qB : PADPK; }
+        QA[j] = qA; QB[j] = qB;
+    }
+    int mA = QA[0], mB = QB[0];
+#pragma unroll
+    for (int j = 1; j < NPL; j++) { mA = pk_min(mA, QA[j]); mB = pk_min(mB, QB[j]); }
+#pragma unroll
+    for (int j = 0; j < NPL; j++) { PA[j] = QA[j]; PB[j] = QB[j]; }
+    const int lo = __builtin_amdgcn_perm(mB, mA, 0x05040100), hi = __builtin_amdgcn_perm(mB, mA, 0x07060302);
+    minAB = pk_grp_allmin<LPC>(pk_min(lo, hi));
+}
+
 // trunc(n / d) for d > 0, |n|, d < 2^23: float reciprocal estimate + exact integer correction
 __device__ __forceinline__ int trunc_div_small(int n, int d) {
     int q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
@@ -686,45 +726,54 @@ __global__ void __launch_bounds__(64) k_vscan(const int *__restrict__ cvol, cons
 //            runs over the same registers and streams L_left + L_right to HBM.
 // HBM traffic per row: C read twice, sum written once, + 2 * 8 B * 64 * W1/K of checkpoints (6 % at K = 32).
 // A tail of W1 % K columns uses the v1 scheme (L_left parked in the output row).
-template <int NP, int K, bool PADDED>
+template <int NPL, int LPC, int K, bool PADDED>
 __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int *__restrict__ hvol, int *__restrict__ ckpt, SgmGeom g) {
-    constexpr int NPW = NP * 64, CKW = (NP + 1) * 64;
-    const int lane = threadIdx.x, y = blockIdx.x;
-    const int *crow = cvol + (size_t)y * g.W1 * NPW + lane * NP;
-    int *hrow = hvol + (size_t)y * g.W1 * NPW + lane * NP;
+    constexpr int DPW = NPL * LPC, RPW = 64 / LPC, CKW = (NPL + 1) * 64;   // words per column, rows per wave
+    const int lane = threadIdx.x, k = lane % LPC;
+    const int yraw = blockIdx.x * RPW + lane / LPC;
+    const bool row_ok = yraw < g.H;
+    const int y = min(yraw, g.H - 1);
+    const int *crow = cvol + (size_t)y * g.W1 * DPW + k * NPL;
+    int *hrow = hvol + (size_t)y * g.W1 * DPW + k * NPL;
     const int W1 = g.W1, nfull = W1 / K, P1pk = pk_dup(g.P1), P2pk = pk_dup(g.P2);
-    int *ck = ckpt + (size_t)y * (nfull + 1) * CKW + lane * (NP + 1);
-    const bool valid = 2 * NP * lane < g.D, first = lane == 0, last = lane == 63;
-    int P[NP], minp = 0;
+    int *ck = ckpt + (size_t)blockIdx.x * (nfull + 1) * CKW + lane * (NPL + 1);
+    const bool valid = 2 * NPL * k < g.D, first = k == 0, last = k == LPC - 1;
+    int P[NPL], minp = 0;
     // four rotating cost buffers: a segment is requested two rounds (2*K steps) before its first use and is never
     // touched in between, so the loads stay in flight across whole rounds
-    int c0[K][NP], c1[K][NP], c2[K][NP], c3[K][NP], llA[K][NP], llB[K][NP];
+    int c0[K][NPL], c1[K][NPL], c2[K][NPL], c3[K][NPL], llA[K][NPL], llB[K][NPL];
 #pragma unroll
-    for (int j = 0; j < NP; j++) P[j] = valid ? 0 : PADPK;
-    auto load_seg = [&](int (&buf)[K][NP], int sidx) {
+    for (int j = 0; j < NPL; j++) P[j] = valid ? 0 : PADPK;
+    auto load_seg = [&](int (&buf)[K][NPL], int sidx) {
         const int sc = min(max(sidx, 0), max(nfull - 1, 0));
-        const int *p = crow + (size_t)sc * K * NPW;
+        const int *p = crow + (size_t)sc * K * DPW;
 #pragma unroll
         for (int u = 0; u < K; u++)
 #pragma unroll
-            for (int j = 0; j < NP; j++) buf[u][j] = p[(size_t)u * NPW + j];
+            for (int j = 0; j < NPL; j++) buf[u][j] = p[(size_t)u * DPW + j];
     };
     auto save_ck = [&](int sidx) {
 #pragma unroll
-        for (int j = 0; j < NP; j++) ck[(size_t)sidx * CKW + j] = P[j];
-        ck[(size_t)sidx * CKW + NP] = minp;
+        for (int j = 0; j < NPL; j++) ck[(size_t)sidx * CKW + j] = P[j];
+        ck[(size_t)sidx * CKW + NPL] = minp;
     };
     auto load_ck = [&](int sidx) {
 #pragma unroll
-        for (int j = 0; j < NP; j++) P[j] = ck[(size_t)sidx * CKW + j];
-        minp = ck[(size_t)sidx * CKW + NP];
+        for (int j = 0; j < NPL; j++) P[j] = ck[(size_t)sidx * CKW + j];
+        minp = ck[(size_t)sidx * CKW + NPL];
+    };
+    auto store_sum = [&](int *dst, const int (&a)[NPL], const int (&b)[NPL]) {
+        if (row_ok) {
+#pragma unroll
+            for (int j = 0; j < NPL; j++) dst[j] = pk_add(a[j], b[j]);
+        }
     };
     // ---- phase 1: forward chain, checkpoint the state entering every segment
-    auto fwd_round = [&](int (&cur)[K][NP], int (&pre)[K][NP], int sidx) {   // pre <- segment sidx+3
+    auto fwd_round = [&](int (&cur)[K][NPL], int (&pre)[K][NPL], int sidx) {   // pre <- segment sidx+3
         load_seg(pre, sidx + 3);
         save_ck(sidx);
 #pragma unroll
-        for (int u = 0; u < K; u++) sgm_step_g<NP, 64, PADDED>(P, minp, cur[u], P1pk, g.P2, first, last, valid);
+        for (int u = 0; u < K; u++) sgm_step_g<NPL, LPC, PADDED>(P, minp, cur[u], P1pk, g.P2, first, last, valid);
     };
     if (nfull > 0) {
         load_seg(c0, 0); load_seg(c1, 1); load_seg(c2, 2);
@@ -736,75 +785,65 @@ __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int
             if (s0 + 3 < nfull) fwd_round(c3, c2, s0 + 3);
         }
     }
-    // tail columns [nfull*K, W1): forward values parked in the output row
+    // tail columns [nfull*K, W1): forward values parked in the output row (rows beyond the image park nothing: they
+    // recompute nothing useful either, their results are never stored)
     for (int x = nfull * K; x < W1; x++) {
-        int c[NP];
+        int c[NPL];
 #pragma unroll
-        for (int j = 0; j < NP; j++) c[j] = crow[(size_t)x * NPW + j];
-        sgm_step_g<NP, 64, PADDED>(P, minp, c, P1pk, g.P2, first, last, valid);
+        for (int j = 0; j < NPL; j++) c[j] = crow[(size_t)x * DPW + j];
+        sgm_step_g<NPL, LPC, PADDED>(P, minp, c, P1pk, g.P2, first, last, valid);
+        if (row_ok) {
 #pragma unroll
-        for (int j = 0; j < NP; j++) hrow[(size_t)x * NPW + j] = P[j];
+            for (int j = 0; j < NPL; j++) hrow[(size_t)x * DPW + j] = P[j];
+        }
     }
     // ---- phase 2: backward chain of segment s in lockstep with the recomputed forward chain of segment s-1
-    int R[NP], minr = 0;
+    int R[NPL], minr = 0;
 #pragma unroll
-    for (int j = 0; j < NP; j++) R[j] = valid ? 0 : PADPK;
+    for (int j = 0; j < NPL; j++) R[j] = valid ? 0 : PADPK;
     for (int x = W1 - 1; x >= nfull * K; x--) {
-        int c[NP];
+        int c[NPL], l[NPL];
 #pragma unroll
-        for (int j = 0; j < NP; j++) c[j] = crow[(size_t)x * NPW + j];
-        sgm_step_g<NP, 64, PADDED>(R, minr, c, P1pk, g.P2, first, last, valid);
-#pragma unroll
-        for (int j = 0; j < NP; j++) hrow[(size_t)x * NPW + j] = pk_add(hrow[(size_t)x * NPW + j], R[j]);
+        for (int j = 0; j < NPL; j++) { c[j] = crow[(size_t)x * DPW + j]; l[j] = hrow[(size_t)x * DPW + j]; }
+        sgm_step_g<NPL, LPC, PADDED>(R, minr, c, P1pk, g.P2, first, last, valid);
+        store_sum(hrow + (size_t)x * DPW, l, R);
     }
     // round(s): A = costs of segment s (backward), B = costs of segment s-1 (forward), pre <- segment s-3
-    auto bwd_round = [&](int (&A)[K][NP], int (&B)[K][NP], int (&pre)[K][NP], int sidx) {
+    auto bwd_round = [&](int (&A)[K][NPL], int (&B)[K][NPL], int (&pre)[K][NPL], int sidx) {
         load_seg(pre, sidx - 3);
-        int *hp = hrow + (size_t)sidx * K * NPW;
+        int *hp = hrow + (size_t)sidx * K * DPW;
         if (sidx > 0) {
             load_ck(sidx - 1);
-            if constexpr (NP == 1) {
-                int mAB = (minr & 0xffff) | (minp << 16);
+            int mAB = (minr & 0xffff) | (minp << 16);
 #pragma unroll
-                for (int u = 0; u < K; u++) {
-                    sgm_step_dual<PADDED>(R[0], P[0], mAB, A[K - 1 - u][0], B[u][0], P1pk, P2pk, valid);
-                    hp[(size_t)(K - 1 - u) * NPW] = pk_add(llA[K - 1 - u][0], R[0]);
-                    llB[u][0] = P[0];
-                }
-                minr = lo16(mAB);
-                minp = hi16(mAB);
-            } else {
+            for (int u = 0; u < K; u++) {
+                sgm_step_dual_g<NPL, LPC, PADDED>(R, P, mAB, A[K - 1 - u], B[u], P1pk, P2pk, first, last, valid);
+                store_sum(hp + (size_t)(K - 1 - u) * DPW, llA[K - 1 - u], R);
 #pragma unroll
-                for (int u = 0; u < K; u++) {
-                    sgm_step_g<NP, 64, PADDED>(R, minr, A[K - 1 - u], P1pk, g.P2, first, last, valid);
-#pragma unroll
-                    for (int j = 0; j < NP; j++) hp[(size_t)(K - 1 - u) * NPW + j] = pk_add(llA[K - 1 - u][j], R[j]);
-                    sgm_step_g<NP, 64, PADDED>(P, minp, B[u], P1pk, g.P2, first, last, valid);
-#pragma unroll
-                    for (int j = 0; j < NP; j++) llB[u][j] = P[j];
-                }
+                for (int j = 0; j < NPL; j++) llB[u][j] = P[j];
             }
+            minr = lo16(mAB);
+            minp = hi16(mAB);
         } else {
 #pragma unroll
             for (int u = 0; u < K; u++) {
-                sgm_step_g<NP, 64, PADDED>(R, minr, A[K - 1 - u], P1pk, g.P2, first, last, valid);
-#pragma unroll
-                for (int j = 0; j < NP; j++) hp[(size_t)(K - 1 - u) * NPW + j] = pk_add(llA[K - 1 - u][j], R[j]);
+                sgm_step_g<NPL, LPC, PADDED>(R, minr, A[K - 1 - u], P1pk, g.P2, first, last, valid);
+                store_sum(hp + (size_t)(K - 1 - u) * DPW, llA[K - 1 - u], R);
             }
         }
 #pragma unroll
         for (int u = 0; u < K; u++)
 #pragma unroll
-            for (int j = 0; j < NP; j++) llA[u][j] = llB[u][j];
+            for (int j = 0; j < NPL; j++) llA[u][j] = llB[u][j];
     };
     if (nfull > 0) {
         load_seg(c0, nfull - 1); load_seg(c1, nfull - 2); load_seg(c2, nfull - 3);
         load_ck(nfull - 1);
 #pragma unroll
         for (int u = 0; u < K; u++) {
-            sgm_step_g<NP, 64, PADDED>(P, minp, c0[u], P1pk, g.P2, first, last, valid);
+            sgm_step_g<NPL, LPC, PADDED>(P, minp, c0[u], P1pk, g.P2, first, last, valid);
 #pragma unroll
-            for (int j = 0; j < NP; j++) llA[u][j] = P[j];
+            for (int j = 0; j < NPL; j++) llA[u][j] = P[j];
         }
 #pragma unroll 1
         for (int s = nfull - 1; s >= 0; s -= 4) {
@@ -1042,6 +1081,43 @@ __global__ void __launch_bounds__(64) k_selftest(int *out) {
             if (dA != PA[0] || dB != PB[0] || lo16(mAB) != mA || hi16(mAB) != mB) bad |= 1 << 23;
         }
     }
+    // generic dual step (2 registers x 32 lanes) == two generic single steps
+    {
+        const int kk = lane % 32;
+        int PA[2] = {(((lane * 7) % 13) & 0xffff) | ((((lane * 5) % 11)) << 16), ((lane * 3) % 19) | (((lane + 4) % 23) << 16)};
+        int PB[2] = {(((lane * 3) % 17) & 0xffff) | ((((lane * 11) % 7)) << 16), ((lane * 9) % 29) | (((lane * 2 + 1) % 31) << 16)};
+        int mA = grp_allmin<32>(min(min(lo16(PA[0]), hi16(PA[0])), min(lo16(PA[1]), hi16(PA[1]))));
+        int mB = grp_allmin<32>(min(min(lo16(PB[0]), hi16(PB[0])), min(lo16(PB[1]), hi16(PB[1]))));
+        const int CA[2] = {((lane + 3) & 0xffff) | ((2 * lane + 1) << 16), (lane % 7) | ((lane % 5) << 16)};
+        const int CB[2] = {((5 * lane + 2) & 0xffff) | ((lane + 9) << 16), (lane % 3) | ((lane % 11) << 16)};
+        int dA[2] = {PA[0], PA[1]}, dB[2] = {PB[0], PB[1]}, mAB = (mA & 0xffff) | (mB << 16);
+        for (int it = 0; it < 3; it++) {
+            sgm_step_g<2, 32, false>(PA, mA, CA, pk_dup(3), 9, kk == 0, kk == 31, true);
+            sgm_step_g<2, 32, false>(PB, mB, CB, pk_dup(3), 9, kk == 0, kk == 31, true);
+            sgm_step_dual_g<2, 32, false>(dA, dB, mAB, CA, CB, pk_dup(3), pk_dup(9), kk == 0, kk == 31, true);
+            if (dA[0] != PA[0] || dA[1] != PA[1] || dB[0] != PB[0] || dB[1] != PB[1] || lo16(mAB) != mA || hi16(mAB) != mB) bad |= 1 << 24;
+        }
+        // and the 2x32 single step against the scalar definition
+        int Q[2] = {(((lane * 7) % 13) & 0xffff) | ((((lane * 5) % 11)) << 16), ((lane * 3) % 19) | (((lane + 4) % 23) << 16)};
+        auto Lp = [&](int grp, int d) -> int {
+            if (d < 0 || d > 127) return 32767;
+            const int l = grp * 32 + d / 4, r = (d / 2) % 2, hh = d % 2;
+            const int v0 = (((l * 7) % 13) & 0xffff) | ((((l * 5) % 11)) << 16), v1 = ((l * 3) % 19) | (((l + 4) % 23) << 16);
+            const int v = r ? v1 : v0;
+            return hh ? hi16(v) : lo16(v);
+        };
+        int mq = grp_allmin<32>(min(min(lo16(Q[0]), hi16(Q[0])), min(lo16(Q[1]), hi16(Q[1]))));
+        const int mq0 = mq;
+        sgm_step_g<2, 32, false>(Q, mq, CA, pk_dup(3), 9, kk == 0, kk == 31, true);
+        for (int r = 0; r < 2; r++)
+            for (int hh = 0; hh < 2; hh++) {
+                const int d = 4 * kk + 2 * r + hh, grp = lane / 32;
+                const int mm = min(min(Lp(grp, d), mq0 + 9), min(Lp(grp, d - 1), Lp(grp, d + 1)) + 3);
+                const int c = hh ? hi16(CA[r]) : lo16(CA[r]);
+                const int got = hh ? hi16(Q[r]) : lo16(Q[r]);
+                if (got != c + mm - (mq0 + 9)) bad |= 1 << 25;
+            }
+    }
     // generic group helpers (v2 kernels), LPC = 8 and 16
     {
         auto val = [](int l) { return (l * 37 + 11) % 101 - 50; };
@@ -1066,6 +1142,44 @@ __global__ void __launch_bounds__(64) k_selftest(int *out) {
         if (!(T * aa >= thr && (T - 1) * aa < thr)) bad |= 1 << 22;
     }
     atomicOr(out, bad);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_streambench (diagnostic, not on the product path): every wave streams through its own `row_bytes`-long row,
+// MODE 0: 4 B/lane requests (256 B per wave-instruction, the access shape of k_hscan), MODE 1: 16 B/lane (1 KB);
+// `write` adds a store of the same shape to a second buffer.  Used to price access shapes.
+template <int MODE>
+__global__ void __launch_bounds__(64) k_streambench(const int *__restrict__ in, int *__restrict__ out, size_t row_words, int write, int delay) {
+    const int lane = threadIdx.x;
+    const int *r = in + (size_t)blockIdx.x * row_words;
+    int *o = out + (size_t)blockIdx.x * row_words;
+    int acc = 0;
+    if (MODE == 0) {
+        for (size_t x = 0; x + 64 * 16 <= row_words; x += 64 * 16) {
+            int v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = r[x + u * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                acc += v[u];
+                for (int d = 0; d < delay; d++) acc = __builtin_amdgcn_update_dpp(acc, acc, 0xB1, 0xf, 0xf, false) + 1;
+                if (write) o[x + u * 64 + lane] = acc;
+            }
+        }
+    } else {
+        for (size_t x = 0; x + 256 * 4 <= row_words; x += 256 * 4) {
+            int4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = *(const int4 *)&r[x + u * 256 + lane * 4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                acc += v[u].x + v[u].y + v[u].z + v[u].w;
+                for (int d = 0; d < 4 * delay; d++) acc = __builtin_amdgcn_update_dpp(acc, acc, 0xB1, 0xf, 0xf, false) + 1;
+                if (write) *(int4 *)&o[x + u * 256 + lane * 4] = make_int4(acc, acc, acc, acc);
+            }
+        }
+    }
+    if (acc == 0x12345678) out[0] = acc;
 }
 
 int derive_geom(r3d_ctx *ctx, const r3d_sgbm_params *p, int w, int h, SgmGeom &g) {
@@ -1148,6 +1262,28 @@ int launch_cost2(r3d_ctx *ctx, const SgmGeom &g, hipStream_t st) {
 
 }  // namespace
 
+int r3d_streambench_run(r3d_ctx *ctx, int mode, int rows, size_t row_bytes, int write, int delay, int reps, float *ms) {
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t row_words = row_bytes / 4, bytes = (size_t)rows * row_bytes;
+    int rc;
+    if ((rc = r3d_reserve(ctx, ctx->cost, bytes)) || (rc = r3d_reserve(ctx, ctx->hsum, bytes))) return rc;
+    hipEvent_t a, b;
+    R3D_HIP(ctx, hipEventCreate(&a));
+    R3D_HIP(ctx, hipEventCreate(&b));
+    for (int i = 0; i < reps + 1; i++) {
+        if (i == 1) R3D_HIP(ctx, hipEventRecord(a, ctx->stream));
+        if (mode == 0) k_streambench<0><<<rows, 64, 0, ctx->stream>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, row_words, write, delay);
+        else k_streambench<1><<<rows, 64, 0, ctx->stream>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, row_words, write, delay);
+    }
+    R3D_HIP(ctx, hipEventRecord(b, ctx->stream));
+    R3D_HIP(ctx, hipEventSynchronize(b));
+    R3D_HIP(ctx, hipEventElapsedTime(ms, a, b));
+    *ms /= reps;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return R3D_OK;
+}
+
 int r3d_selftest_run(r3d_ctx *ctx) {
     R3D_HIP(ctx, hipSetDevice(ctx->device));
     if (int rc = r3d_reserve(ctx, ctx->flags, 256)) return rc;
@@ -1219,18 +1355,20 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
         if (g.NP == 1) k_hscan<1><<<h, 64, 0, st>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, g);
         else k_hscan<2><<<h, 64, 0, st>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, g);
     } else {
-        constexpr int K1 = 16, K2 = 8;
+        // D <= 128: 2 registers x 32 lanes per row (2 rows per wave); D <= 256: 4 x 32
+        constexpr int K1 = 12, K2 = 6;
         const int K = g.NP == 1 ? K1 : K2;
         const bool padded = g.D != 128 * g.NP;
-        if ((rc = r3d_reserve(ctx, ctx->ckpt, (size_t)h * (g.W1 / K + 1) * (g.NP + 1) * 64 * 4))) return rc;
+        const int nwaves = (h + 1) / 2;
+        if ((rc = r3d_reserve(ctx, ctx->ckpt, (size_t)nwaves * (g.W1 / K + 1) * (2 * g.NP + 1) * 64 * 4))) return rc;
         const int *cp = (const int *)ctx->cost.p;
         int *hp = (int *)ctx->hsum.p, *kp = (int *)ctx->ckpt.p;
         if (g.NP == 1) {
-            if (padded) k_hscan2<1, K1, true><<<h, 64, 0, st>>>(cp, hp, kp, g);
-            else k_hscan2<1, K1, false><<<h, 64, 0, st>>>(cp, hp, kp, g);
+            if (padded) k_hscan2<2, 32, K1, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
+            else k_hscan2<2, 32, K1, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
         } else {
-            if (padded) k_hscan2<2, K2, true><<<h, 64, 0, st>>>(cp, hp, kp, g);
-            else k_hscan2<2, K2, false><<<h, 64, 0, st>>>(cp, hp, kp, g);
+            if (padded) k_hscan2<4, 32, K2, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
+            else k_hscan2<4, 32, K2, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
         }
     }
     R3D_HIP(ctx, hipGetLastError());

@@ -39,6 +39,8 @@ const char *r3d_last_error(const r3d_ctx *ctx); /* ctx may be NULL: returns the 
 int r3d_sync(r3d_ctx *ctx);                     /* hipStreamSynchronize on the ctx stream */
 int r3d_set_stream(r3d_ctx *ctx, void *hip_stream /* hipStream_t, NULL = ctx-owned stream */);
 void *r3d_get_stream(r3d_ctx *ctx);
+/* diagnostic: prices an access shape (rows independent streams of row_bytes; mode 0 = 256 B, 1 = 1 KB per wave request) */
+int r3d_debug_streambench(r3d_ctx *ctx, int32_t mode, int32_t rows, uint64_t row_bytes, int32_t write, int32_t delay, int32_t reps, float *ms);
 /* checks the cross-lane primitives (DPP shifts, permlane swaps, wave reductions) the kernels rely on */
 int r3d_selftest(r3d_ctx *ctx);
 
