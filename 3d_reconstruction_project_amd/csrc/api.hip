@@ -88,7 +88,7 @@ void r3d_destroy(r3d_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     r3d_buf *bufs[] = {&ctx->img_l, &ctx->img_r, &ctx->rec_l, &ctx->rec_r, &ctx->cost, &ctx->cspec, &ctx->hsum, &ctx->ckpt,
-                       &ctx->raw, &ctx->mins, &ctx->lrd, &ctx->out, &ctx->flags};
+                       &ctx->raw, &ctx->mins, &ctx->lrd, &ctx->out, &ctx->flags, &ctx->spk_l, &ctx->spk_c};
     for (r3d_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (r3d_buf &b : ctx->cloud_bufs)
@@ -216,6 +216,20 @@ int r3d_sgbm_compute(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *left
     R3D_HIP(ctx, hipMemcpyAsync(ctx->img_r.p, right, ib, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = r3d_sgm_run(ctx, p, (const uint8_t *)ctx->img_l.p, (const uint8_t *)ctx->img_r.p, w, h, stride, (int16_t *)ctx->out.p))) return rc;
     R3D_HIP(ctx, hipMemcpyAsync(disp, ctx->out.p, ob, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return R3D_OK;
+}
+
+int r3d_filter_speckles(r3d_ctx *ctx, int16_t *img, int32_t w, int32_t h, int32_t new_val, int32_t max_speckle_size, int32_t max_diff) {
+    if (!ctx) return R3D_E_BADARG;
+    if (!img || w <= 0 || h <= 0) return r3d_fail(ctx, R3D_E_BADARG, "filter_speckles: bad argument");
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)w * h * 2;
+    int rc;
+    if ((rc = r3d_reserve(ctx, ctx->out, bytes))) return rc;
+    R3D_HIP(ctx, hipMemcpyAsync(ctx->out.p, img, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = r3d_speckle_run(ctx, (int16_t *)ctx->out.p, w, h, new_val, max_speckle_size, max_diff))) return rc;
+    R3D_HIP(ctx, hipMemcpyAsync(img, ctx->out.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return R3D_OK;
 }

@@ -371,7 +371,9 @@ __global__ void __launch_bounds__(ICP_BLOCK) k_icp_eval(GridView g, const double
                 for (int j = b; j < e; j++) {
                     double dx = g.pts[(int64_t)j * 3] - px, dy = g.pts[(int64_t)j * 3 + 1] - py, dz = g.pts[(int64_t)j * 3 + 2] - pz;
                     double d2 = dx * dx + dy * dy + dz * dz;
-                    if (d2 < best || (d2 == best && bi >= 0 && g.idx[j] < g.idx[bi])) { best = d2; bi = j; }
+                    if (d2 <= best) {   // ties are rare: the index loads of the total order (d2, index) stay off the hot path
+                        if (d2 < best || (bi >= 0 && g.idx[j] < g.idx[bi])) { best = d2; bi = j; }
+                    }
                 }
             });
             const double reach = s * g.cell;
@@ -462,11 +464,13 @@ __global__ void __launch_bounds__(ICP_BLOCK) k_icp_eval(GridView g, const double
     }
 }
 
+// one wave per slot: lane t adds the partials t, t+64, ... in order, then a fixed shuffle tree => deterministic
 __global__ void __launch_bounds__(64) k_icp_final(const double *__restrict__ partial, int nblocks, double *__restrict__ out) {
-    if (threadIdx.x >= ICP_SLOTS) return;
+    const int slot = blockIdx.x;
     double v = 0;
-    for (int b = 0; b < nblocks; b++) v += partial[(size_t)b * ICP_SLOTS + threadIdx.x];  // fixed order: deterministic
-    out[threadIdx.x] = v;
+    for (int b = threadIdx.x; b < nblocks; b += 64) v += partial[(size_t)b * ICP_SLOTS + slot];
+    v = wave_sum(v);
+    if (threadIdx.x == 0) out[slot] = v;
 }
 
 __global__ void __launch_bounds__(256) k_transform(const double *__restrict__ in, int64_t n, Rigid T, int rotate_only, double *__restrict__ out) {
@@ -987,7 +991,7 @@ int r3d_icp(r3d_ctx *ctx, const r3d_icp_params *p, const double *src, int64_t ns
             case MODE_P2PLANE: k_icp_eval<MODE_P2PLANE><<<nblocks, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, p->max_correspondence_distance, eps, d_part, nullptr); break;
             default: k_icp_eval<MODE_GICP><<<nblocks, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, p->max_correspondence_distance, eps, d_part, nullptr); break;
         }
-        k_icp_final<<<1, 64, 0, ctx->stream>>>(d_part, nblocks, d_sum);
+        k_icp_final<<<ICP_SLOTS, 64, 0, ctx->stream>>>(d_part, nblocks, d_sum);
         R3D_HIP(ctx, hipGetLastError());
         R3D_HIP(ctx, hipMemcpyAsync(sums, d_sum, sizeof sums, hipMemcpyDeviceToHost, ctx->stream));
         R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -30,7 +30,7 @@ struct r3d_ctx {
     std::string err;
     bool profiling = false;
     // grow-only workspace
-    r3d_buf img_l, img_r, rec_l, rec_r, cost, cspec, hsum, ckpt, raw, mins, lrd, out, flags;
+    r3d_buf img_l, img_r, rec_l, rec_r, cost, cspec, hsum, ckpt, raw, mins, lrd, out, flags, spk_l, spk_c;
     // geometry of the last sgbm call (for debug fetch)
     int last_w = 0, last_h = 0, last_w1 = 0, last_dp = 0;
     // profiling: ring of event sets so that harvesting never stalls the stream; sums accumulate per kernel name
@@ -89,4 +89,5 @@ static inline void r3d_prof_end(r3d_ctx *ctx) {
 int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, const uint8_t *d_right, int w, int h,
                 int stride, int16_t *d_disp);
 int r3d_selftest_run(r3d_ctx *ctx);
+int r3d_speckle_run(r3d_ctx *ctx, int16_t *d_img, int w, int h, int newVal, int maxSize, int maxDiff);
 int r3d_streambench_run(r3d_ctx *ctx, int mode, int rows, size_t row_bytes, int write, int delay, int reps, float *ms);

@@ -409,9 +409,10 @@ __global__ void __launch_bounds__(COST_NW * 64) k_cost(const uint2 *__restrict__
 // Borders: columns clamp in cost coordinates, rows clamp to [clampTop, h-1] (replication, as the original).
 constexpr int COST2_NWAVE = 8;
 
-template <int LPC, int SH2>
+template <int LPC, int SH2, bool TRACK>
 __global__ void __launch_bounds__(COST2_NWAVE * 64) k_cost2(const uint2 *__restrict__ recL, const uint2 *__restrict__ recR, SgmGeom g,
-                                                            int *__restrict__ cvol, int *__restrict__ cspec, int BAND, int nMain) {
+                                                            int *__restrict__ cvol, int *__restrict__ cspec, int BAND, int nMain,
+                                                            int *__restrict__ maxc) {
     constexpr int NPL = 8, CW = 64 / LPC, TC = COST2_NWAVE * CW, TO = TC - 2 * SH2, DP = 16 * LPC, DPW = NPL * LPC;
     constexpr int R = 2 * SH2 + 1, NRR = TC + DP, NT = COST2_NWAVE * 64;
     // pair words: 6 dwords per right pixel, plus 8 dwords of padding after every 16 pixels: lanes of one column group
@@ -488,6 +489,7 @@ __global__ void __launch_bounds__(COST2_NWAVE * 64) k_cost2(const uint2 *__restr
     const bool is_out = cl >= SH2 && cl < TC - SH2 && (t0 - SH2 + cl) < g.W1;
     int *optr = obase + (size_t)(t0 - SH2 + cl) * DPW + k * NPL;
     const int tile_x0 = t0 - SH2;
+    int cmax = 0;   // TRACK: running maximum of every emitted block cost (exact-arithmetic envelope check on the host)
     stage(crow(y0 - SH2), 0);
     __syncthreads();
     // iteration t: row e = y0 - SH2 + t enters the window (inputs in buffer t&1, staged one iteration earlier);
@@ -534,7 +536,15 @@ __global__ void __launch_bounds__(COST2_NWAVE * 64) k_cost2(const uint2 *__restr
             int *o = optr + (size_t)(t - 2 * SH2) * rowWords;
             *(int4 *)o = make_int4(c[0], c[1], c[2], c[3]);
             *(int4 *)(o + 4) = make_int4(c[4], c[5], c[6], c[7]);
+            if (TRACK && 16 * k < g.D) {
+#pragma unroll
+                for (int j = 0; j < NPL; j++) cmax = pk_umax(cmax, c[j]);
+            }
         }
+    }
+    if (TRACK) {
+        const int m = wave_allmax_i32(max(cmax & 0xffff, (int)((unsigned)cmax >> 16)));
+        if (lane == 0) atomicMax(maxc, m);
     }
 }
 
@@ -1024,6 +1034,56 @@ __global__ void __launch_bounds__(256) k_median3(const int16_t *__restrict__ src
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// filterSpeckles(disp, newVal, maxSpeckleSize, maxDiff) (called by StereoSGBM.compute iff speckleWindowSize > 0, the
+// depth4.py / depth_test.py parameter family): 4-connected components of pixels != newVal whose neighbouring values
+// differ by <= maxDiff; components of at most maxSpeckleSize pixels are set to newVal.  The original flood-fills in
+// raster order; component membership does not depend on the order, so a lock-free union-find gives the same image.
+__device__ __forceinline__ int uf_find(int *L, int i) {
+    int p = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != i) { i = p; p = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    return i;
+}
+__device__ __forceinline__ void uf_union(int *L, int a, int b) {
+    for (;;) {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }   // link the larger root to the smaller one
+        const int old = atomicMin(&L[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+__global__ void __launch_bounds__(256) k_spk_init(const int16_t *__restrict__ img, int n, int newVal, int *__restrict__ L, int *__restrict__ cnt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    L[i] = img[i] != newVal ? i : -1;
+    cnt[i] = 0;
+}
+__global__ void __launch_bounds__(256) k_spk_merge(const int16_t *__restrict__ img, int W, int H, int newVal, int maxDiff, int *__restrict__ L) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int i = y * W + x, v = img[i];
+    if (v == newVal) return;
+    if (x + 1 < W) { const int u = img[i + 1]; if (u != newVal && abs(v - u) <= maxDiff) uf_union(L, i, i + 1); }
+    if (y + 1 < H) { const int u = img[i + W]; if (u != newVal && abs(v - u) <= maxDiff) uf_union(L, i, i + W); }
+}
+__global__ void __launch_bounds__(256) k_spk_count(int n, int *__restrict__ L, int *__restrict__ cnt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || L[i] < 0) return;
+    const int r = uf_find(L, i);
+    L[i] = r;                       // flatten (every thread only shortens its own entry)
+    atomicAdd(&cnt[r], 1);
+}
+__global__ void __launch_bounds__(256) k_spk_apply(int16_t *__restrict__ img, int n, int newVal, int maxSize, const int *__restrict__ L,
+                                                   const int *__restrict__ cnt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = L[i];
+    if (r >= 0 && cnt[r] <= maxSize) img[i] = (int16_t)newVal;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // k_selftest: checks the cross-lane building blocks against their definition.
 __global__ void __launch_bounds__(64) k_selftest(int *out) {
     const int lane = threadIdx.x;
@@ -1212,24 +1272,26 @@ int derive_geom(r3d_ctx *ctx, const r3d_sgbm_params *p, int w, int h, SgmGeom &g
     g.overlap = (p->blockSize / 2 + 1) + (g.stripe_sz + 9) / 10;
     g.invalid = (g.minD - 1) * 16;
     // exact-int16 envelope (DESIGN.md "arithmetic envelope"): no packed add may wrap
+    // static half: the block cost must fit int16 at all and P2 <= 16383; when the worst-case block cost exceeds 16383
+    // the cost kernel tracks the actual maximum and the call fails loudly only if THIS image pair leaves the envelope
     const long cmax = (long)p->blockSize * p->blockSize * (2L * g.ftzero + 63);
-    if (cmax > 16383 || g.P2 > 16383 || g.ftzero > 127)
+    if (cmax > 32767 || g.P2 > 16383 || g.ftzero > 127)
         return r3d_fail(ctx, R3D_E_UNSUPPORTED,
-                        "sgbm: blockSize=%d preFilterCap=%d P2=%d leave the exact int16 envelope (max block cost %ld > 16383 or P2 > 16383)",
+                        "sgbm: blockSize=%d preFilterCap=%d P2=%d leave the exact int16 envelope (max block cost %ld > 32767 or P2 > 16383)",
                         p->blockSize, p->preFilterCap, g.P2, cmax);
     if ((long)g.minD * 16 - 16 < -32768 || ((long)maxD) * 16 > 32767)
         return r3d_fail(ctx, R3D_E_BADARG, "sgbm: disparity range [%d, %d) does not fit the x16 int16 output", g.minD, maxD);
     return R3D_OK;
 }
 
-template <int LPC, int SH2>
+template <int LPC, int SH2, bool TRACK>
 int launch_cost2_t(r3d_ctx *ctx, const SgmGeom &g, hipStream_t st) {
     constexpr int CW = 64 / LPC, TC = COST2_NWAVE * CW, TO = TC - 2 * SH2;
     static_assert(TO > 0, "tile too small for this block size");
     const int tiles = (g.W1 + TO - 1) / TO;
     // size the row bands so that one round of workgroups fills the chip (each band pays 2*SH2 extra rows of pixel cost)
     int per_cu = 1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_cost2<LPC, SH2>, COST2_NWAVE * 64, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_cost2<LPC, SH2, TRACK>, COST2_NWAVE * 64, 0);
     if (per_cu < 1) per_cu = 1;
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
@@ -1240,20 +1302,31 @@ int launch_cost2_t(r3d_ctx *ctx, const SgmGeom &g, hipStream_t st) {
     if (BAND < 16) BAND = 16;
     const int nMain = (g.H + BAND - 1) / BAND;
     const int nSpec = SH2 > 0 ? 3 : 0;
-    k_cost2<LPC, SH2><<<dim3(tiles, nMain + nSpec), COST2_NWAVE * 64, 0, st>>>((const uint2 *)ctx->rec_l.p, (const uint2 *)ctx->rec_r.p, g,
-                                                                                 (int *)ctx->cost.p, (int *)ctx->cspec.p, BAND, nMain);
+    int *maxc = (int *)ctx->flags.p + 8;
+    if (TRACK) R3D_HIP(ctx, hipMemsetAsync(maxc, 0, 4, st));
+    k_cost2<LPC, SH2, TRACK><<<dim3(tiles, nMain + nSpec), COST2_NWAVE * 64, 0, st>>>((const uint2 *)ctx->rec_l.p, (const uint2 *)ctx->rec_r.p, g,
+                                                                                        (int *)ctx->cost.p, (int *)ctx->cspec.p, BAND, nMain, maxc);
     R3D_HIP(ctx, hipGetLastError());
+    if (TRACK) {
+        // data-dependent half of the exact-int16 envelope: only reached when the static bound cannot prove it
+        int m = 0;
+        R3D_HIP(ctx, hipMemcpyAsync(&m, maxc, 4, hipMemcpyDeviceToHost, st));
+        R3D_HIP(ctx, hipStreamSynchronize(st));
+        if (m > 16383)
+            return r3d_fail(ctx, R3D_E_UNSUPPORTED, "sgbm: block cost reaches %d > 16383 on this image pair; outside the exact int16 envelope", m);
+    }
     return R3D_OK;
 }
 template <int LPC>
 int launch_cost2_l(r3d_ctx *ctx, const SgmGeom &g, hipStream_t st) {
+    const bool track = (long)(2 * g.SH2 + 1) * (2 * g.SH2 + 1) * (2L * g.ftzero + 63) > 16383;
     switch (g.SH2) {
-        case 0: return launch_cost2_t<LPC, 0>(ctx, g, st);
-        case 1: return launch_cost2_t<LPC, 1>(ctx, g, st);
-        case 2: return launch_cost2_t<LPC, 2>(ctx, g, st);
-        case 3: return launch_cost2_t<LPC, 3>(ctx, g, st);
-        case 4: return launch_cost2_t<LPC, 4>(ctx, g, st);
-        default: return launch_cost2_t<LPC, 5>(ctx, g, st);
+        case 0: return launch_cost2_t<LPC, 0, false>(ctx, g, st);
+        case 1: return launch_cost2_t<LPC, 1, false>(ctx, g, st);
+        case 2: return launch_cost2_t<LPC, 2, false>(ctx, g, st);
+        case 3: return track ? launch_cost2_t<LPC, 3, true>(ctx, g, st) : launch_cost2_t<LPC, 3, false>(ctx, g, st);
+        case 4: return track ? launch_cost2_t<LPC, 4, true>(ctx, g, st) : launch_cost2_t<LPC, 4, false>(ctx, g, st);
+        default: return launch_cost2_t<LPC, 5, true>(ctx, g, st);
     }
 }
 int launch_cost2(r3d_ctx *ctx, const SgmGeom &g, hipStream_t st) {
@@ -1284,6 +1357,21 @@ int r3d_streambench_run(r3d_ctx *ctx, int mode, int rows, size_t row_bytes, int 
     return R3D_OK;
 }
 
+int r3d_speckle_run(r3d_ctx *ctx, int16_t *d_img, int w, int h, int newVal, int maxSize, int maxDiff) {
+    const size_t n = (size_t)w * h;
+    if (n > 0x7fffffff) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "filterSpeckles: image too large");
+    int rc;
+    if ((rc = r3d_reserve(ctx, ctx->spk_l, n * 4)) || (rc = r3d_reserve(ctx, ctx->spk_c, n * 4))) return rc;
+    int *L = (int *)ctx->spk_l.p, *C = (int *)ctx->spk_c.p;
+    const int nb = (int)((n + 255) / 256);
+    k_spk_init<<<nb, 256, 0, ctx->stream>>>(d_img, (int)n, newVal, L, C);
+    k_spk_merge<<<dim3((w + 255) / 256, h), 256, 0, ctx->stream>>>(d_img, w, h, newVal, maxDiff, L);
+    k_spk_count<<<nb, 256, 0, ctx->stream>>>((int)n, L, C);
+    k_spk_apply<<<nb, 256, 0, ctx->stream>>>(d_img, (int)n, newVal, maxSize, L, C);
+    R3D_HIP(ctx, hipGetLastError());
+    return R3D_OK;
+}
+
 int r3d_selftest_run(r3d_ctx *ctx) {
     R3D_HIP(ctx, hipSetDevice(ctx->device));
     if (int rc = r3d_reserve(ctx, ctx->flags, 256)) return rc;
@@ -1303,8 +1391,6 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
     if (int rc = derive_geom(ctx, p, w, h, g)) return rc;
     if (!d_left || !d_right || !d_disp) return r3d_fail(ctx, R3D_E_BADARG, "sgbm: null image pointer");
     if (stride < w) return r3d_fail(ctx, R3D_E_BADARG, "sgbm: stride %d < width %d", stride, w);
-    if (p->speckleWindowSize > 0)
-        return r3d_fail(ctx, R3D_E_UNSUPPORTED, "sgbm: speckleWindowSize > 0 (filterSpeckles) is not implemented yet");
     R3D_HIP(ctx, hipSetDevice(ctx->device));
     const int NPW = g.NP * 64;
     const size_t npix = (size_t)w * h;
@@ -1321,6 +1407,7 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
     if ((rc = r3d_reserve(ctx, ctx->lrd, npix * 2))) return rc;
     ctx->last_w = w; ctx->last_h = h; ctx->last_w1 = g.W1; ctx->last_dp = NPW * 2;
     hipStream_t st = ctx->stream;
+    if ((rc = r3d_reserve(ctx, ctx->flags, 256))) return rc;
     r3d_prof_begin(ctx);
 
     r3d_prof_mark(ctx, "prefilter");
@@ -1392,6 +1479,10 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
     r3d_prof_mark(ctx, "median3");
     k_median3<<<dim3((w + 255) / 256, h), 256, 0, st>>>((const int16_t *)ctx->lrd.p, d_disp, w, h);
     R3D_HIP(ctx, hipGetLastError());
+    if (p->speckleWindowSize > 0) {
+        r3d_prof_mark(ctx, "speckles");
+        if ((rc = r3d_speckle_run(ctx, d_disp, w, h, g.invalid, p->speckleWindowSize, 16 * p->speckleRange))) return rc;
+    }
     r3d_prof_end(ctx);
     return R3D_OK;
 }

@@ -106,6 +106,15 @@ class StereoSGBM:
         return out
 
 
+def filterSpeckles(img, newVal, maxSpeckleSize, maxDiff, device=0):
+    """cv2.filterSpeckles on an int16 image; returns the filtered copy."""
+    a = np.ascontiguousarray(img, dtype=np.int16).copy()
+    H, W = a.shape
+    _lib.default_context(_lib.parse_device(device)).call("r3d_filter_speckles", a.ctypes.data_as(ctypes.c_void_p), W, H,
+                                                         int(newVal), int(maxSpeckleSize), int(maxDiff))
+    return a
+
+
 def StereoSGBM_create(minDisparity=0, numDisparities=16, blockSize=3, P1=0, P2=0, disp12MaxDiff=0, preFilterCap=0,
                       uniquenessRatio=0, speckleWindowSize=0, speckleRange=0, mode=STEREO_SGBM_MODE_SGBM, device=0):
     """Factory with cv2.StereoSGBM_create's keyword names and defaults.  Only MODE_SGBM_3WAY is implemented (the

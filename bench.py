@@ -29,6 +29,8 @@ ALG_BYTES = {
     "vscan_wta": 2 * W1 * H * D + 4 * W * H,  # the one compulsory volume READ + disparity/cost out
     "cost": 2 * W * H,                        # reads both images; the cost volume itself is not algorithmic
 }
+KERNEL_OF = {"cost": "k_cost2", "hscan": "k_hscan2", "vscan_wta": "k_vscan2", "prefilter": "k_prefilter",
+             "lrcheck": "k_lrcheck", "median3": "k_median3"}
 
 
 def bench_gicp(r3d, ctx, n=1_000_000, iters=20, cpu=True):
@@ -133,10 +135,14 @@ def main():
             traffic = None
             tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
             if os.path.exists(tp):
+                # HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE doubled: gfx950 tallies 128-B requests at
+                # 64 B, MI355X_MICROARCH.md "HBM"; WRITE_SIZE as is; both in KiB), written by tools/pmc_summary.py
                 with open(tp) as f:
-                    traffic = json.load(f).get(dom)
+                    t = json.load(f).get(KERNEL_OF.get(dom, dom))
+                if t and "FETCH_SIZE" in t and "WRITE_SIZE" in t:
+                    traffic = round((2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024 / 1e9, 3)
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK / 1e9,
-                        "unit": "GB/s", "frac": round(ach * 1e9 / HBM_PEAK, 4), "traffic": traffic,
+                        "unit": "GB/s", "frac": round(ach * 1e9 / HBM_PEAK, 4), "traffic": traffic, "traffic_unit": "GB/launch",
                         "kernel_ms": {k: round(v, 4) for k, v in prof.items()},
                         "pipeline_frac": round(ALG_BYTES["map"] * (args.steps / (dev_ms * 1e-3)) / HBM_PEAK, 4)}
         cpu = None

@@ -82,6 +82,10 @@ int r3d_sgbm_compute(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *left
 int r3d_sgbm_compute_dev(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, const uint8_t *d_right,
                          int32_t w, int32_t h, int32_t stride, int16_t *d_disp);
 
+/* cv2.filterSpeckles(img, newVal, maxSpeckleSize, maxDiff) on an int16 image, in place (host buffer): the last stage of
+ * StereoSGBM.compute when speckleWindowSize > 0 (Calib_depth/depth4.py:164-165, depth_test.py:170-171) */
+int r3d_filter_speckles(r3d_ctx *ctx, int16_t *img, int32_t w, int32_t h, int32_t new_val, int32_t max_speckle_size, int32_t max_diff);
+
 /* per-kernel HIP-event timing (events on the ctx stream around every kernel launch while profiling is enabled).
  * r3d_sgbm_profile returns, and then resets, the AVERAGE launch duration per kernel over all r3d_sgbm_compute*
  * calls since the previous r3d_sgbm_profile.  names: NUL-separated list, one entry per slot; ms: one float per

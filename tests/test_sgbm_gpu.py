@@ -35,7 +35,7 @@ def test_bit_exact_vs_oracle(r3d, synth, W, H, D, seed):
     assert got.dtype == np.int16 and (got[:, :D] == -16).all()
 
 
-@pytest.mark.parametrize("bs", [1, 3, 7, 9])
+@pytest.mark.parametrize("bs", [1, 3, 7, 9, 11])
 def test_block_sizes(r3d, synth, bs):
     D = 32
     L, R, _ = synth.stereo_pair(260, 110, D, seed=20 + bs)
@@ -77,6 +77,31 @@ def test_setters_follow_key_handler_protocol(r3d, synth):
     m.setBlockSize(7)
     kw = dict(C2_KW, blockSize=7)
     np.testing.assert_array_equal(m.compute(L, R), _oracle(L, R, 64, kw))
+
+
+D4_KW = dict(minDisparity=0, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1, uniquenessRatio=10,
+             speckleWindowSize=50, speckleRange=32, preFilterCap=63)                  # Calib_depth/depth4.py:156-168
+
+
+def test_filter_speckles_matches_oracle(r3d):
+    from oracle import sgbm_oracle as so
+    rng = np.random.default_rng(3)
+    img = (rng.integers(0, 6, (300, 500)) * 40).astype(np.int16)
+    img[rng.random(img.shape) < 0.25] = -16
+    for size, diff in ((6, 32), (50, 512), (1, 0), (100000, 39)):
+        np.testing.assert_array_equal(r3d.stereo_sgbm.filterSpeckles(img, -16, size, diff), so.filter_speckles(img, -16, size, diff))
+
+
+@pytest.mark.parametrize("W,H,D,seed", [(320, 240, 32, 0), (640, 480, 128, 1)])
+def test_depth4_parameter_family_with_speckle_filter(r3d, synth, W, H, D, seed):
+    L, R, _ = synth.stereo_pair(W, H, D, seed=seed, noise=6.0)         # noisy => speckles exist
+    got = _gpu(r3d, D, D4_KW).compute(L, R)
+    want = _oracle(L, R, D, D4_KW)
+    np.testing.assert_array_equal(got, want)
+    no_filter = _oracle(L, R, D, dict(D4_KW, speckleWindowSize=0))
+    assert (want != no_filter).any()                                     # the filter actually removed something
+    m = r3d.reference_matcher(numDisparities=D, blockSize=5, family="depth4")
+    np.testing.assert_array_equal(m.compute(L, R), want)
 
 
 def test_errors_are_loud(r3d):
