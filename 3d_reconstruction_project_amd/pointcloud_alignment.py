@@ -62,3 +62,26 @@ class GeneralizedICPAlignment:
 
 def align(source, target, **kw):
     return PointCloudAlignment(verbose=False).align_point_clouds(source, target, **kw)
+
+
+def multi_scale_icp(source, target, voxel_size, init=None, scales=(15.0, 5.0, 1.5), iterations=(30, 20, 10),
+                    source_normals=None, target_normals=None, verbose=False):
+    """Multi-scale point-to-plane refinement of test/check2.py:143-156 (same loop in check_lama1.py:287-290,
+    mini1.py:293-296): registration_icp(PointToPlane) at max_correspondence_distance = voxel_size * scale, each scale
+    starting from the previous result; ICPConvergenceCriteria(max_iteration=n) keeps the 1e-6 relative defaults.
+    Returns (T, per-scale result dicts)."""
+    sp, _, sn = as_arrays(source)
+    tp, _, tn = as_arrays(target)
+    tn = target_normals if target_normals is not None else tn
+    if tn is None:
+        raise ValueError("point-to-plane ICP needs target normals (the reference estimates them in preprocess_point_cloud)")
+    T = np.eye(4) if init is None else np.asarray(init, dtype=np.float64)
+    results = []
+    for scale, n_it in zip(scales, iterations):
+        dist = voxel_size * scale
+        if verbose:
+            print(f"ICP at scale {len(results)}, max correspondence distance: {dist}")
+        res = cloud_ops.registration(sp, tp, dist, T, cloud_ops.P2PLANE, n_it, 1e-6, 1e-6, None, tn)
+        T = res["T"]
+        results.append(res)
+    return T, results

@@ -123,6 +123,16 @@ def StereoSGBM_create(minDisparity=0, numDisparities=16, blockSize=3, P1=0, P2=0
                       speckleWindowSize, speckleRange, mode, device)
 
 
+def createRightMatcher(matcher_left):
+    """cv2.ximgproc.createRightMatcher(matcher_left) (Calib_depth/depth1.py:215, depth2.py:161): a StereoSGBM with
+    minDisparity = -(minD + D) + 1, the same D / blockSize / P1 / P2 / preFilterCap / mode, uniquenessRatio 0,
+    disp12MaxDiff 1000000 and no speckle filter; it is called as compute(right, left) (depth2.py:252)."""
+    p = matcher_left._p
+    return StereoSGBM(minDisparity=-(p["minDisparity"] + p["numDisparities"]) + 1, numDisparities=p["numDisparities"],
+                      blockSize=p["blockSize"], P1=p["P1"], P2=p["P2"], disp12MaxDiff=1000000, preFilterCap=p["preFilterCap"],
+                      uniquenessRatio=0, speckleWindowSize=0, speckleRange=0, mode=p["mode"], device=matcher_left._device)
+
+
 def reference_matcher(numDisparities=128, blockSize=5, family="depth2", device=0):
     """The two parameter families the reference uses (Calib_depth/depth2.py:139-158, depth4.py:147-168)."""
     kw = dict(minDisparity=0, numDisparities=numDisparities, blockSize=blockSize, P1=8 * 3 * blockSize ** 2,

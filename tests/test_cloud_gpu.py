@@ -199,3 +199,47 @@ def test_normal_estimation_drop_in(r3d):
     from scipy.spatial import cKDTree
     _, idx = cKDTree(p32).query(p32, k=2)
     assert ((n * n[idx[:, 1]]).sum(1) > 0).mean() > 0.98
+
+
+def test_multi_scale_point_to_plane(r3d, synth):
+    """test/check2.py:143-156: three scales [15, 5, 1.5] * voxel with [30, 20, 10] iterations, each from the previous."""
+    rng = np.random.default_rng(4)
+    sc = np.array([1.0, 0.7, 0.5])
+    tgt = _sphere(15000, 1, 0.3) * sc + rng.normal(0, 2e-4, (15000, 3))
+    T = synth.rigid((0.3, -0.5, 0.8), 6.0, (0.03, -0.02, 0.025))
+    src = co.transform_points(np.linalg.inv(T), _sphere(12000, 2, 0.3) * sc + rng.normal(0, 2e-4, (12000, 3)))
+    tn = co.estimate_normals_knn(tgt, 20)
+    voxel = 0.004
+    Tg, results = r3d.multi_scale_icp(r3d.PointCloud(src), r3d.PointCloud(tgt, normals=tn), voxel)
+    Tw = np.eye(4)
+    for scale, n_it, got in zip((15.0, 5.0, 1.5), (30, 20, 10), results):
+        want = co.registration(src, tgt, voxel * scale, init=Tw, mode="p2plane", max_iteration=n_it, target_normals=tn)
+        Tw = want["T"]
+        assert got["iterations"] == want["iterations"] and np.abs(got["T"] - want["T"]).max() < 1e-8
+    R_err = Tg[:3, :3] @ T[:3, :3].T
+    assert np.degrees(np.arccos(np.clip((np.trace(R_err) - 1) / 2, -1, 1))) < 0.05
+
+
+def test_cloud_edge_cases(r3d):
+    co_g = r3d.cloud_ops
+    one = np.array([[0.1, 0.2, 0.3]])
+    p, _, _ = co_g.voxel_down_sample(one, 0.01)
+    assert np.array_equal(p, one)
+    assert (co_g.estimate_normals(one, 0.05, 30) == [[0, 0, 1]]).all()
+    few = np.array([[0, 0, 0], [0.01, 0, 0], [0, 0.01, 0], [0.01, 0.01, 0.0]])
+    n = co_g.estimate_normals(few, 0.05, 30)
+    assert np.abs(np.abs(n[:, 2]) - 1).max() < 1e-12                      # coplanar points: normal = +-z
+    dup = np.repeat(few, 5, axis=0)                                       # exact duplicates: distance ties everywhere
+    np.testing.assert_array_equal(co_g.voxel_down_sample(dup, 0.5)[0], co.voxel_down_sample(dup, 0.5))
+    nbr, d2 = co_g.knn_graph(dup, 7)
+    np.testing.assert_array_equal(nbr, co._nearest_total_order(dup, dup, 7)[0])
+    empty = co_g.voxel_down_sample(np.zeros((0, 3)), 0.01)[0]
+    assert empty.shape == (0, 3)
+    with pytest.raises(r3d.R3DError):
+        co_g.registration(np.zeros((0, 3)), few, 0.02)
+    with pytest.raises(r3d.R3DError):
+        co_g.registration(few, few, 0.02, mode=co_g.P2PLANE)             # point-to-plane without target normals
+    with pytest.raises(r3d.R3DError):
+        co_g.registration(few, few, -1.0)
+    res = co_g.registration(few, few, 0.02, max_iteration=0)
+    assert res["iterations"] == 0 and res["fitness"] == 1.0 and np.array_equal(res["T"], np.eye(4))

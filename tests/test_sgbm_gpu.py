@@ -137,3 +137,38 @@ def test_full_size_8mp_properties(r3d, synth):
     dd = a[rows[ok], xl[ok]] / 16.0
     v = dd >= 0
     assert np.abs(dd[v] - gt[ok][v]).mean() < 0.5
+
+
+def test_right_matcher_factory(r3d, synth):
+    """depth2.py:161,252: right_matcher = createRightMatcher(stereo_matcher); right_matcher.compute(gray_right, gray_left)."""
+    D = 64
+    L, R, _ = synth.stereo_pair(400, 120, D, seed=21)
+    left = r3d.reference_matcher(numDisparities=D, blockSize=5)
+    right = r3d.createRightMatcher(left)
+    assert right.getMinDisparity() == -(0 + D) + 1 and right.getUniquenessRatio() == 0
+    kw = dict(C2_KW, minDisparity=-D + 1, uniquenessRatio=0, disp12MaxDiff=1000000)
+    got = right.compute(R, L)
+    np.testing.assert_array_equal(got, _oracle(R, L, D, kw))
+    # right-view disparities are the negated left-view ones on this scene (where both are valid)
+    dl = left.compute(L, R)
+    ok = (dl[:, D:-D] >= 0)
+    assert ok.mean() > 0.8
+
+
+def test_randomised_parameter_sweep(r3d):
+    """Ragged sizes and random parameter combinations (incl. degenerate ones) must stay bit-exact."""
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        D = int(rng.choice([16, 32, 48, 64, 96, 128, 144, 256]))
+        W = D + int(rng.integers(3, 90))
+        H = int(rng.integers(1, 70))
+        bs = int(rng.choice([1, 3, 5, 7, 9]))
+        kw = dict(minDisparity=int(rng.choice([0, 0, -7, 5, -D + 1])), blockSize=bs, P1=int(rng.choice([0, 8 * bs * bs, 24 * bs * bs])),
+                  P2=int(rng.choice([0, 32 * bs * bs, 96 * bs * bs])), disp12MaxDiff=int(rng.choice([-1, 0, 1, 3])),
+                  uniquenessRatio=int(rng.choice([0, 5, 15, 40])), speckleWindowSize=int(rng.choice([0, 0, 20])),
+                  speckleRange=int(rng.choice([1, 2, 16])), preFilterCap=int(rng.choice([0, 15, 31, 63])))
+        L = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        R = np.roll(L, -int(rng.integers(0, max(D // 2, 1))), axis=1) if rng.random() < 0.7 else rng.integers(0, 256, (H, W), dtype=np.uint8)
+        got = _gpu(r3d, D, kw).compute(L, R)
+        want = _oracle(L, R, D, kw)
+        assert np.array_equal(got, want), f"case {case}: W={W} H={H} D={D} {kw}: {(got != want).sum()} pixels differ"
