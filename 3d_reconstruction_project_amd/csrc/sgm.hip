@@ -1002,14 +1002,16 @@ __global__ void __launch_bounds__(256) k_lrcheck(const int16_t *__restrict__ raw
             if (d1 != g.invalid) {
                 const int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
                 const int _x = x - _d, x_ = x - d_;
+                // QUIRK: an unset disp2 entry holds the SCALED invalid marker (minD-1)*16, which passes the ">= minD"
+                // test whenever minD >= 2 and then counts as a disagreeing match
                 bool f1 = false, f2 = false;
-                if (0 <= _x && _x < W && keys[_x] != 0xffffffffu) {
-                    const int d2 = (W - 1 - (int)(keys[_x] & 0xffffu)) - _x;  // disp2[_x] (>= minD by construction)
-                    f1 = abs(d2 - _d) > g.d12;
+                if (0 <= _x && _x < W) {
+                    const int d2 = keys[_x] != 0xffffffffu ? (W - 1 - (int)(keys[_x] & 0xffffu)) - _x : g.invalid;
+                    f1 = d2 >= g.minD && abs(d2 - _d) > g.d12;
                 }
-                if (0 <= x_ && x_ < W && keys[x_] != 0xffffffffu) {
-                    const int d2 = (W - 1 - (int)(keys[x_] & 0xffffu)) - x_;
-                    f2 = abs(d2 - d_) > g.d12;
+                if (0 <= x_ && x_ < W) {
+                    const int d2 = keys[x_] != 0xffffffffu ? (W - 1 - (int)(keys[x_] & 0xffffu)) - x_ : g.invalid;
+                    f2 = d2 >= g.minD && abs(d2 - d_) > g.d12;
                 }
                 if (f1 && f2) d1 = g.invalid;
             }

@@ -282,7 +282,8 @@ static int run_stripe(const uint8_t *L, const uint8_t *R, int ldL, int ldR, cons
             drow[x + g->minX1] = (int16_t)(dsp + g->minD * DISP_SCALE);
         }
         if (!drow) continue;
-        /* --- pseudo left-right consistency check on this row */
+        /* --- pseudo left-right consistency check on this row.  QUIRK: disp2 was initialised with the SCALED invalid
+         *     marker (minD-1)*16, which passes the ">= minD" test whenever minD >= 2 */
         for (int x = g->minX1; x < g->maxX1; x++) {
             int d1 = drow[x];
             if (d1 == INVALID) continue;

@@ -27,6 +27,7 @@ def test_constant_shift_known_answer(synth):
     (C2_KW, 16, (24, 48), 0), (C2_KW, 32, (21, 70), 1), (D4_KW, 16, (30, 52), 2),
     (dict(C2_KW, blockSize=3, P1=72, P2=288), 16, (17, 40), 3),
     (dict(C2_KW, blockSize=7, P1=8 * 3 * 49, P2=32 * 3 * 49, uniquenessRatio=0), 16, (26, 44), 4),
+    (dict(C2_KW, minDisparity=5, blockSize=3, P1=216, P2=288, uniquenessRatio=0), 16, (23, 60), 5),   # minD >= 2: disp2 marker quirk
 ])
 def test_c_oracle_equals_numpy_restatement(kw, D, shape, seed, synth):
     H, W = shape
