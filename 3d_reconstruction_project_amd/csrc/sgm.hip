@@ -967,12 +967,21 @@ __global__ void __launch_bounds__(64) k_vscan2(const int *__restrict__ cvol, con
             mins[o] = (int16_t)minS;
         }
     };
+    // four row buffers in rotation: a row is requested three rows (~3 x 900 cycles) before it is consumed
+    int c2[NPL], h2[NPL], c3[NPL], h3[NPL];
     load_row(src_start, cc, hh);
-    for (int y = src_start; y < src_end; y += 2) {
-        load_row(y + 1, cn, hn);
+    load_row(src_start + 1, cn, hn);
+    load_row(src_start + 2, c2, h2);
+#pragma unroll 1
+    for (int y = src_start; y < src_end; y += 4) {
+        load_row(y + 3, c3, h3);
         process(y, cc, hh);
-        load_row(y + 2, cc, hh);
+        load_row(y + 4, cc, hh);
         if (y + 1 < src_end) process(y + 1, cn, hn);
+        load_row(y + 5, cn, hn);
+        if (y + 2 < src_end) process(y + 2, c2, h2);
+        load_row(y + 6, c2, h2);
+        if (y + 3 < src_end) process(y + 3, c3, h3);
     }
 }
 

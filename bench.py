@@ -87,7 +87,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("R3D_FORCE_DIST"):      # R3D_FORCE_DIST: rehearse the multi-rank code path with one rank
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
