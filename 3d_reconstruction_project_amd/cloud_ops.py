@@ -16,6 +16,7 @@ _lib.register({
     "r3d_reproject_disparity": ([_vp, _vp, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _vp,
                                  ctypes.POINTER(ctypes.c_int64)], ctypes.c_int),
     "r3d_knn_graph": ([_vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_double, _vp, _vp], ctypes.c_int),
+    "r3d_orient_normals": ([_vp, _vp, ctypes.c_int64, ctypes.c_int32, _vp], ctypes.c_int),
     "r3d_transform_points": ([_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int32, _vp], ctypes.c_int),
     "r3d_icp": ([_vp, ctypes.POINTER(_lib.IcpParams), _vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp,
                  ctypes.POINTER(_lib.IcpStats)], ctypes.c_int),
@@ -88,6 +89,15 @@ def knn_graph(points, k, radius=0.0, want_d2=True, ctx=None):
     d2 = np.empty((len(p), k)) if want_d2 else None
     ctx.call("r3d_knn_graph", _ptr(p), len(p), k, float(radius), nbr.ctypes.data_as(_vp), _ptr(d2))
     return nbr, d2
+
+
+def orient_normals(points, normals, k=100, ctx=None):
+    """orient_normals_consistent_tangent_plane(k): returns the re-oriented copy of `normals`."""
+    ctx = ctx or _lib.default_context()
+    p = _c(points)
+    n = np.ascontiguousarray(normals, dtype=np.float64).reshape(-1, 3).copy()
+    ctx.call("r3d_orient_normals", _ptr(p), len(p), int(k), _ptr(n))
+    return n
 
 
 def statistical_outlier_mask(points, nb_neighbors, std_ratio, ctx=None):

@@ -913,6 +913,79 @@ int r3d_knn_graph(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, double 
     return R3D_OK;
 }
 
+// orient_normals_consistent_tangent_plane(k): device k-NN graph, then sequential host work in C++ (Kruskal minimum
+// spanning tree over the edges weighted 1 - |n_i . n_j|, breadth-first sign propagation from the highest point of every
+// component).  Deterministic: edges are ordered by (weight, i, j).
+int r3d_orient_normals(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, double *normals) {
+    if (!ctx) return R3D_E_BADARG;
+    if (!xyz || !normals || n <= 0 || k < 1) return r3d_fail(ctx, R3D_E_BADARG, "orient_normals: bad argument");
+    if (n == 1) { if (normals[2] < 0) for (int a = 0; a < 3; a++) normals[a] = -normals[a]; return R3D_OK; }
+    const int kk = (int)std::min<int64_t>((int64_t)k + 1, std::min<int64_t>(n, 128));
+    std::vector<int32_t> nbr((size_t)n * kk);
+    int rc = r3d_knn_graph(ctx, xyz, n, kk, -1.0, nbr.data(), nullptr);
+    if (rc) return rc;
+    struct Edge { double w; int a, b; };
+    std::vector<Edge> edges;
+    edges.reserve((size_t)n * (kk - 1));
+    auto dotn = [&](int a, int b) { return normals[(size_t)a * 3] * normals[(size_t)b * 3] + normals[(size_t)a * 3 + 1] * normals[(size_t)b * 3 + 1] + normals[(size_t)a * 3 + 2] * normals[(size_t)b * 3 + 2]; };
+    for (int64_t i = 0; i < n; i++)
+        for (int j = 1; j < kk; j++) {
+            const int q = nbr[(size_t)i * kk + j];
+            if (q < 0 || q == i) continue;
+            const int a = (int)std::min<int64_t>(i, q), b = (int)std::max<int64_t>(i, q);
+            edges.push_back({1.0 - std::fabs(dotn(a, b)), a, b});
+        }
+    std::sort(edges.begin(), edges.end(), [](const Edge &x, const Edge &y) {
+        if (x.w != y.w) return x.w < y.w;
+        if (x.a != y.a) return x.a < y.a;
+        return x.b < y.b;
+    });
+    std::vector<int> parent(n);
+    for (int64_t i = 0; i < n; i++) parent[i] = (int)i;
+    auto find = [&](int v) { while (parent[v] != v) { parent[v] = parent[parent[v]]; v = parent[v]; } return v; };
+    std::vector<int> deg(n + 1, 0);
+    std::vector<std::pair<int, int>> tree;
+    tree.reserve(n);
+    for (const Edge &e : edges) {
+        const int ra = find(e.a), rb = find(e.b);
+        if (ra == rb) continue;
+        parent[ra] = rb;
+        tree.push_back({e.a, e.b});
+        deg[e.a + 1]++; deg[e.b + 1]++;
+    }
+    for (int64_t i = 0; i < n; i++) deg[i + 1] += deg[i];
+    std::vector<int> adj(tree.size() * 2), fill(deg.begin(), deg.end() - 1);
+    for (auto &t : tree) { adj[fill[t.first]++] = t.second; adj[fill[t.second]++] = t.first; }
+    // components: root = highest z
+    std::vector<int> comp_root(n, -1);
+    for (int64_t i = 0; i < n; i++) {
+        const int r = find((int)i);
+        if (comp_root[r] < 0 || xyz[(size_t)i * 3 + 2] > xyz[(size_t)comp_root[r] * 3 + 2]) comp_root[r] = (int)i;
+    }
+    std::vector<char> seen(n, 0);
+    std::vector<int> queue;
+    queue.reserve(n);
+    for (int64_t r = 0; r < n; r++) {
+        const int root = comp_root[r];
+        if (root < 0) continue;
+        if (normals[(size_t)root * 3 + 2] < 0) for (int a = 0; a < 3; a++) normals[(size_t)root * 3 + a] = -normals[(size_t)root * 3 + a];
+        queue.clear();
+        queue.push_back(root);
+        seen[root] = 1;
+        for (size_t h = 0; h < queue.size(); h++) {
+            const int v = queue[h];
+            for (int e = deg[v]; e < deg[v + 1]; e++) {
+                const int u = adj[e];
+                if (seen[u]) continue;
+                seen[u] = 1;
+                if (dotn(u, v) < 0) for (int a = 0; a < 3; a++) normals[(size_t)u * 3 + a] = -normals[(size_t)u * 3 + a];
+                queue.push_back(u);
+            }
+        }
+    }
+    return R3D_OK;
+}
+
 int r3d_transform_points(r3d_ctx *ctx, const double *xyz, int64_t n, const double *T4x4, int32_t rotate_only, double *out) {
     if (!ctx) return R3D_E_BADARG;
     if (!xyz || !out || !T4x4 || n <= 0) return r3d_fail(ctx, R3D_E_BADARG, "transform_points: bad argument");

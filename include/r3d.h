@@ -133,6 +133,10 @@ int r3d_reproject_disparity(r3d_ctx *ctx, const int16_t *disp, int32_t w, int32_
  * (normal_estimation.py:21), whose spanning-tree propagation is sequential host work.  d2 may be NULL. */
 int r3d_knn_graph(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, double radius, int32_t *nbr, double *d2);
 
+/* replaces: pcd.orient_normals_consistent_tangent_plane(k)   normal_estimation.py:21.  k-NN graph on the device, spanning
+ * tree + sign propagation (sequential) on the host inside the library; normals are flipped in place. */
+int r3d_orient_normals(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, double *normals);
+
 /* replaces: pcd.transform(T)   pointcloud_alignment.py:42  (rotate_only != 0 for normals) ; T row-major 4x4 */
 int r3d_transform_points(r3d_ctx *ctx, const double *xyz, int64_t n, const double *T4x4, int32_t rotate_only, double *out);
 

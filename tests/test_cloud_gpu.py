@@ -243,3 +243,15 @@ def test_cloud_edge_cases(r3d):
         co_g.registration(few, few, -1.0)
     res = co_g.registration(few, few, 0.02, max_iteration=0)
     assert res["iterations"] == 0 and res["fitness"] == 1.0 and np.array_equal(res["T"], np.eye(4))
+
+
+def test_orient_normals_makes_a_closed_surface_consistent(r3d):
+    p = _sphere(8000, 7, 0.5)
+    rng = np.random.default_rng(1)
+    n = p / np.linalg.norm(p, axis=1, keepdims=True) * np.where(rng.random(len(p)) < 0.5, -1.0, 1.0)[:, None]
+    out = r3d.cloud_ops.orient_normals(p, n, 12)
+    s = np.sign((out * p).sum(1))
+    assert abs(s.mean()) == 1.0                         # all outward or all inward
+    assert s[np.argmax(p[:, 2])] == 1.0                 # seeded at the highest point, turned towards +z
+    np.testing.assert_array_equal(np.abs(out), np.abs(n))
+    np.testing.assert_array_equal(out, r3d.cloud_ops.orient_normals(p, n, 12))     # deterministic
