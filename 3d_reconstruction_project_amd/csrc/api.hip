@@ -87,7 +87,7 @@ void r3d_destroy(r3d_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    r3d_buf *bufs[] = {&ctx->img_l, &ctx->img_r, &ctx->rec_l, &ctx->rec_r, &ctx->cost, &ctx->cspec, &ctx->hsum, &ctx->ckpt,
+    r3d_buf *bufs[] = {&ctx->img_l, &ctx->img_r, &ctx->rec_l, &ctx->rec_r, &ctx->cost, &ctx->cspec, &ctx->hsum, &ctx->ltop, &ctx->ckpt,
                        &ctx->raw, &ctx->mins, &ctx->lrd, &ctx->out, &ctx->flags, &ctx->spk_l, &ctx->spk_c};
     for (r3d_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -240,7 +240,10 @@ int r3d_sgbm_debug_fetch(r3d_ctx *ctx, int16_t *cost, int16_t *hsum, int16_t *ra
     R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const size_t vol = (size_t)ctx->last_h * ctx->last_w1 * ctx->last_dp * 2;
     if (cost) R3D_HIP(ctx, hipMemcpy(cost, ctx->cost.p, vol, hipMemcpyDeviceToHost));
-    if (hsum) R3D_HIP(ctx, hipMemcpy(hsum, ctx->hsum.p, vol, hipMemcpyDeviceToHost));
+    if (hsum) {
+        if (ctx->last_impl == 3) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "debug_fetch: the v3 pipeline never materialises L_left + L_right (set R3D_SGM_IMPL=v2)");
+        R3D_HIP(ctx, hipMemcpy(hsum, ctx->hsum.p, vol, hipMemcpyDeviceToHost));
+    }
     if (raw) R3D_HIP(ctx, hipMemcpy(raw, ctx->lrd.p, (size_t)ctx->last_w * ctx->last_h * 2, hipMemcpyDeviceToHost));
     return R3D_OK;
 }

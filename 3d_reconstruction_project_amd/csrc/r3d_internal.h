@@ -30,9 +30,9 @@ struct r3d_ctx {
     std::string err;
     bool profiling = false;
     // grow-only workspace
-    r3d_buf img_l, img_r, rec_l, rec_r, cost, cspec, hsum, ckpt, raw, mins, lrd, out, flags, spk_l, spk_c;
+    r3d_buf img_l, img_r, rec_l, rec_r, cost, cspec, hsum, ltop, ckpt, raw, mins, lrd, out, flags, spk_l, spk_c;
     // geometry of the last sgbm call (for debug fetch)
-    int last_w = 0, last_h = 0, last_w1 = 0, last_dp = 0;
+    int last_w = 0, last_h = 0, last_w1 = 0, last_dp = 0, last_impl = 0;
     // profiling: ring of event sets so that harvesting never stalls the stream; sums accumulate per kernel name
     r3d_prof_set prof[R3D_PROF_SETS];
     int prof_cur = 0;

@@ -409,10 +409,13 @@ __global__ void __launch_bounds__(COST_NW * 64) k_cost(const uint2 *__restrict__
 // Borders: columns clamp in cost coordinates, rows clamp to [clampTop, h-1] (replication, as the original).
 constexpr int COST2_NWAVE = 8;
 
-template <int LPC, int SH2, bool TRACK>
+// VCH (v3): the vertical path L_top is aggregated right here, on the freshly summed block cost that is still in
+// registers: one workgroup column-tile per STRIPE marches from the stripe's first warm-up row to its last row, and
+// writes C and L_top for the rows the stripe owns (the warm-up rows' special block costs never leave the chip).
+template <int LPC, int SH2, bool TRACK, bool VCH>
 __global__ void __launch_bounds__(COST2_NWAVE * 64) k_cost2(const uint2 *__restrict__ recL, const uint2 *__restrict__ recR, SgmGeom g,
                                                             int *__restrict__ cvol, int *__restrict__ cspec, int BAND, int nMain,
-                                                            int *__restrict__ maxc) {
+                                                            int *__restrict__ maxc, int *__restrict__ ltvol) {
     constexpr int NPL = 8, CW = 64 / LPC, TC = COST2_NWAVE * CW, TO = TC - 2 * SH2, DP = 16 * LPC, DPW = NPL * LPC;
     constexpr int R = 2 * SH2 + 1, NRR = TC + DP, NT = COST2_NWAVE * 64;
     // pair words: 6 dwords per right pixel, plus 8 dwords of padding after every 16 pixels: lanes of one column group
@@ -430,9 +433,16 @@ __global__ void __launch_bounds__(COST2_NWAVE * 64) k_cost2(const uint2 *__restr
     const int r_base = max(t0 - SH2, 0) + g.minX1 - g.minD - (DP - 1);
     const int ri0 = min(max(x - g.minD - 16 * k - r_base, 15), NRR - 1);   // pair-word index of this lane's lowest disparity
     const size_t rowWords = (size_t)g.W1 * DPW;
-    int y0, y1, clampTop;
+    int y0, y1, clampTop, out_start = 0;
     int *obase;
-    if ((int)blockIdx.y < nMain) {
+    if (VCH) {
+        const int n = blockIdx.y;                       // stripe
+        y0 = max(min(n * g.stripe_sz - g.overlap, g.H), 0);
+        y1 = min((n + 1) * g.stripe_sz, g.H);
+        clampTop = y0;
+        out_start = min(n * g.stripe_sz, g.H);
+        obase = cvol + (size_t)y0 * rowWords;
+    } else if ((int)blockIdx.y < nMain) {
         y0 = blockIdx.y * BAND; y1 = min(y0 + BAND, g.H); clampTop = 0;
         obase = cvol + (size_t)y0 * rowWords;
     } else {
@@ -443,6 +453,12 @@ __global__ void __launch_bounds__(COST2_NWAVE * 64) k_cost2(const uint2 *__restr
     }
     if (y0 >= y1) return;
     auto crow = [&](int yy) { return min(max(yy, clampTop), g.H - 1); };
+    // vertical path state (VCH)
+    int LT[NPL], ltmin = 0;
+    const bool lane_valid = 16 * k < g.D;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) LT[j] = lane_valid ? 0 : PADPK;
+    const int P1pk = pk_dup(g.P1);
 
     // (a) staging of image row `row` into buffer b
     auto stage = [&](int row, int b) {
@@ -533,9 +549,21 @@ __global__ void __launch_bounds__(COST2_NWAVE * 64) k_cost2(const uint2 *__restr
                 c[0] = pk_add(c[0], v0.x); c[1] = pk_add(c[1], v0.y); c[2] = pk_add(c[2], v0.z); c[3] = pk_add(c[3], v0.w);
                 c[4] = pk_add(c[4], v1.x); c[5] = pk_add(c[5], v1.y); c[6] = pk_add(c[6], v1.z); c[7] = pk_add(c[7], v1.w);
             }
-            int *o = optr + (size_t)(t - 2 * SH2) * rowWords;
-            *(int4 *)o = make_int4(c[0], c[1], c[2], c[3]);
-            *(int4 *)(o + 4) = make_int4(c[4], c[5], c[6], c[7]);
+            if (VCH) {
+                sgm_step_g<NPL, LPC, true>(LT, ltmin, c, P1pk, g.P2, k == 0, k == LPC - 1, lane_valid);
+                if (y0 + t - 2 * SH2 >= out_start) {
+                    const size_t ro = (size_t)(t - 2 * SH2) * rowWords;
+                    int *o = optr + ro, *l = ltvol + (optr - cvol) + ro;
+                    *(int4 *)o = make_int4(c[0], c[1], c[2], c[3]);
+                    *(int4 *)(o + 4) = make_int4(c[4], c[5], c[6], c[7]);
+                    *(int4 *)l = make_int4(LT[0], LT[1], LT[2], LT[3]);
+                    *(int4 *)(l + 4) = make_int4(LT[4], LT[5], LT[6], LT[7]);
+                }
+            } else {
+                int *o = optr + (size_t)(t - 2 * SH2) * rowWords;
+                *(int4 *)o = make_int4(c[0], c[1], c[2], c[3]);
+                *(int4 *)(o + 4) = make_int4(c[4], c[5], c[6], c[7]);
+            }
             if (TRACK && 16 * k < g.D) {
 #pragma unroll
                 for (int j = 0; j < NPL; j++) cmax = pk_umax(cmax, c[j]);
@@ -861,6 +889,211 @@ __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int
             if (s - 1 >= 0) bwd_round(c1, c2, c0, s - 1);
             if (s - 2 >= 0) bwd_round(c2, c3, c1, s - 2);
             if (s - 3 >= 0) bwd_round(c3, c0, c2, s - 3);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Winner-take-all + uniqueness + sub-pixel for one disparity vector in the generic mapping (group-uniform results).
+// sS: per-wave LDS image (64 * NPL ints) used to fetch the winner's two neighbours with a per-group address.
+template <int NPL, int LPC>
+__device__ __forceinline__ void wta_eval(const int (&S)[NPL], int lane, int k, bool valid, const SgmGeom &g, float inv_a, int *sS,
+                                         int &dsp_out, int &minS_out) {
+    int key = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        const int d0 = 2 * NPL * k + 2 * j;
+        const int k0 = (int)((unsigned)S[j] << 16) | d0;
+        const int k1 = (S[j] & (int)0xffff0000) | (d0 + 1);
+        key = min(key, min(k0, k1));
+    }
+    if (!valid) key = 0x7fffffff;
+    key = grp_allmin<LPC>(key);
+    const int best = key & 0xffff, minS = key >> 16;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NPL; j++) sS[lane * NPL + j] = S[j];
+    __syncthreads();
+    const int gbase = (lane - k) * NPL;
+    const int dm = max(best - 1, 0), dp = min(best + 1, g.D - 1);
+    const int wm = sS[gbase + (dm >> 1)], wp = sS[gbase + (dp >> 1)];
+    const int sm = (dm & 1) ? hi16(wm) : lo16(wm), sp = (dp & 1) ? hi16(wp) : lo16(wp);
+    bool bad = false;
+    if (g.uniq > 0) {
+        const int T = ceil_div_small(minS * 100, 100 - g.uniq, inv_a);
+        int cnt;
+        if (T > 32767) cnt = valid ? 2 * NPL : 0;
+        else {
+            const int Tpk = pk_dup(max(T, -32768));
+            int acc = 0;
+#pragma unroll
+            for (int j = 0; j < NPL; j++) {
+                const int diff = as_i(__builtin_elementwise_sub_sat(as_s(S[j]), as_s(Tpk)));
+                acc = pk_sub(acc, as_i(as_s(diff) >> (s16x2){15, 15}));
+            }
+            cnt = valid ? lo16(acc) + hi16(acc) : 0;
+        }
+        cnt = grp_allsum<LPC>(cnt);
+        int win = (minS < T) ? 1 : 0;
+        if (best > 0 && sm < T) win++;
+        if (best < g.D - 1 && sp < T) win++;
+        bad = cnt > win;
+    }
+    int dsp = g.invalid;
+    if (!bad) {
+        dsp = best * 16;
+        if (0 < best && best < g.D - 1) {
+            const int den = max(sm + sp - 2 * minS, 1);
+            dsp += trunc_div_small((sm - sp) * 16 + den, den * 2);
+        }
+        dsp += g.minD * 16;
+    }
+    dsp_out = dsp;
+    minS_out = minS;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_hscan3 (v3): k_hscan2 whose backward phase finishes the pixel: S = (L_left + L_right) + L_top, winner-take-all,
+// uniqueness and sub-pixel happen in the same step, so only the disparity and its cost leave the kernel -- the
+// L_left + L_right volume is never written.  L_top comes from k_cost2<VCH>; its loads are off the dependency chain.
+template <int NPL, int LPC, int K, bool PADDED>
+__global__ void __launch_bounds__(64) k_hscan3(const int *__restrict__ cvol, const int *__restrict__ ltvol, int *__restrict__ tail,
+                                               int *__restrict__ ckpt, SgmGeom g, float inv_a, int16_t *__restrict__ raw,
+                                               int16_t *__restrict__ mins) {
+    constexpr int DPW = NPL * LPC, RPW = 64 / LPC, CKW = (NPL + 1) * 64;
+    __shared__ int sS[64 * NPL];
+    const int lane = threadIdx.x, k = lane % LPC;
+    const int yraw = blockIdx.x * RPW + lane / LPC;
+    const bool row_ok = yraw < g.H;
+    const int y = min(yraw, g.H - 1);
+    const int *crow = cvol + (size_t)y * g.W1 * DPW + k * NPL;
+    const int *lrow = ltvol + (size_t)y * g.W1 * DPW + k * NPL;
+    int *trow = tail + (size_t)y * K * DPW + k * NPL;                 // parking space of the tail columns' L_left
+    const int W1 = g.W1, nfull = W1 / K, P1pk = pk_dup(g.P1), P2pk = pk_dup(g.P2);
+    int *ck = ckpt + (size_t)blockIdx.x * (nfull + 1) * CKW + lane * (NPL + 1);
+    const bool valid = 2 * NPL * k < g.D, first = k == 0, last = k == LPC - 1;
+    int P[NPL], minp = 0;
+    int c0[K][NPL], c1[K][NPL], c2[K][NPL], c3[K][NPL], llA[K][NPL], llB[K][NPL], ltA[K][NPL], ltB[K][NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; j++) P[j] = valid ? 0 : PADPK;
+    auto load_seg = [&](int (&buf)[K][NPL], const int *row, int sidx) {
+        const int sc = min(max(sidx, 0), max(nfull - 1, 0));
+        const int *p = row + (size_t)sc * K * DPW;
+#pragma unroll
+        for (int u = 0; u < K; u++)
+#pragma unroll
+            for (int j = 0; j < NPL; j++) buf[u][j] = p[(size_t)u * DPW + j];
+    };
+    auto save_ck = [&](int sidx) {
+#pragma unroll
+        for (int j = 0; j < NPL; j++) ck[(size_t)sidx * CKW + j] = P[j];
+        ck[(size_t)sidx * CKW + NPL] = minp;
+    };
+    auto load_ck = [&](int sidx) {
+#pragma unroll
+        for (int j = 0; j < NPL; j++) P[j] = ck[(size_t)sidx * CKW + j];
+        minp = ck[(size_t)sidx * CKW + NPL];
+    };
+    // finishes cost column xcol: S, WTA, stores
+    auto finish = [&](int xcol, const int (&ll)[NPL], const int (&lr)[NPL], const int (&lt)[NPL]) {
+        int S[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; j++) S[j] = pk_add_sat(pk_add(ll[j], lr[j]), lt[j]);
+        int dsp, mS;
+        wta_eval<NPL, LPC>(S, lane, k, valid, g, inv_a, sS, dsp, mS);
+        if (first && row_ok) {
+            const size_t o = (size_t)y * g.W + g.minX1 + xcol;
+            raw[o] = (int16_t)dsp;
+            mins[o] = (int16_t)mS;
+        }
+    };
+    // ---- phase 1: forward chain, checkpoint the state entering every segment
+    auto fwd_round = [&](int (&cur)[K][NPL], int (&pre)[K][NPL], int sidx) {
+        load_seg(pre, crow, sidx + 3);
+        save_ck(sidx);
+#pragma unroll
+        for (int u = 0; u < K; u++) sgm_step_g<NPL, LPC, PADDED>(P, minp, cur[u], P1pk, g.P2, first, last, valid);
+    };
+    if (nfull > 0) {
+        load_seg(c0, crow, 0); load_seg(c1, crow, 1); load_seg(c2, crow, 2);
+#pragma unroll 1
+        for (int s0 = 0; s0 < nfull; s0 += 4) {
+            fwd_round(c0, c3, s0);
+            if (s0 + 1 < nfull) fwd_round(c1, c0, s0 + 1);
+            if (s0 + 2 < nfull) fwd_round(c2, c1, s0 + 2);
+            if (s0 + 3 < nfull) fwd_round(c3, c2, s0 + 3);
+        }
+    }
+    for (int x = nfull * K; x < W1; x++) {
+        int c[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; j++) c[j] = crow[(size_t)x * DPW + j];
+        sgm_step_g<NPL, LPC, PADDED>(P, minp, c, P1pk, g.P2, first, last, valid);
+        if (row_ok) {
+#pragma unroll
+            for (int j = 0; j < NPL; j++) trow[(size_t)(x - nfull * K) * DPW + j] = P[j];
+        }
+    }
+    // ---- phase 2
+    int R[NPL], minr = 0;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) R[j] = valid ? 0 : PADPK;
+    for (int x = W1 - 1; x >= nfull * K; x--) {
+        int c[NPL], l[NPL], t[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; j++) {
+            c[j] = crow[(size_t)x * DPW + j];
+            l[j] = row_ok ? trow[(size_t)(x - nfull * K) * DPW + j] : 0;
+            t[j] = lrow[(size_t)x * DPW + j];
+        }
+        sgm_step_g<NPL, LPC, PADDED>(R, minr, c, P1pk, g.P2, first, last, valid);
+        finish(x, l, R, t);
+    }
+    // round(s): A = costs of segment s (backward), B = costs of segment s-1 (forward), pre <- segment s-3;
+    //           TA = L_top of segment s, TB <- L_top of segment s-1 (one round of lead, off the chain)
+    auto bwd_round = [&](int (&A)[K][NPL], int (&B)[K][NPL], int (&pre)[K][NPL], int (&TA)[K][NPL], int (&TB)[K][NPL], int sidx) {
+        load_seg(pre, crow, sidx - 3);
+        load_seg(TB, lrow, sidx - 1);
+        if (sidx > 0) {
+            load_ck(sidx - 1);
+            int mAB = (minr & 0xffff) | (minp << 16);
+#pragma unroll
+            for (int u = 0; u < K; u++) {
+                sgm_step_dual_g<NPL, LPC, PADDED>(R, P, mAB, A[K - 1 - u], B[u], P1pk, P2pk, first, last, valid);
+                finish(sidx * K + K - 1 - u, llA[K - 1 - u], R, TA[K - 1 - u]);
+#pragma unroll
+                for (int j = 0; j < NPL; j++) llB[u][j] = P[j];
+            }
+            minr = lo16(mAB);
+            minp = hi16(mAB);
+        } else {
+#pragma unroll
+            for (int u = 0; u < K; u++) {
+                sgm_step_g<NPL, LPC, PADDED>(R, minr, A[K - 1 - u], P1pk, g.P2, first, last, valid);
+                finish(sidx * K + K - 1 - u, llA[K - 1 - u], R, TA[K - 1 - u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < K; u++)
+#pragma unroll
+            for (int j = 0; j < NPL; j++) llA[u][j] = llB[u][j];
+    };
+    if (nfull > 0) {
+        load_seg(c0, crow, nfull - 1); load_seg(c1, crow, nfull - 2); load_seg(c2, crow, nfull - 3);
+        load_seg(ltA, lrow, nfull - 1);
+        load_ck(nfull - 1);
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            sgm_step_g<NPL, LPC, PADDED>(P, minp, c0[u], P1pk, g.P2, first, last, valid);
+#pragma unroll
+            for (int j = 0; j < NPL; j++) llA[u][j] = P[j];
+        }
+#pragma unroll 1
+        for (int s = nfull - 1; s >= 0; s -= 4) {
+            bwd_round(c0, c1, c3, ltA, ltB, s);
+            if (s - 1 >= 0) bwd_round(c1, c2, c0, ltB, ltA, s - 1);
+            if (s - 2 >= 0) bwd_round(c2, c3, c1, ltA, ltB, s - 2);
+            if (s - 3 >= 0) bwd_round(c3, c0, c2, ltB, ltA, s - 3);
         }
     }
 }
@@ -1295,14 +1528,14 @@ int derive_geom(r3d_ctx *ctx, const r3d_sgbm_params *p, int w, int h, SgmGeom &g
     return R3D_OK;
 }
 
-template <int LPC, int SH2, bool TRACK>
+template <int LPC, int SH2, bool TRACK, bool VCH>
 int launch_cost2_t(r3d_ctx *ctx, const SgmGeom &g, hipStream_t st) {
     constexpr int CW = 64 / LPC, TC = COST2_NWAVE * CW, TO = TC - 2 * SH2;
     static_assert(TO > 0, "tile too small for this block size");
     const int tiles = (g.W1 + TO - 1) / TO;
     // size the row bands so that one round of workgroups fills the chip (each band pays 2*SH2 extra rows of pixel cost)
     int per_cu = 1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_cost2<LPC, SH2, TRACK>, COST2_NWAVE * 64, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_cost2<LPC, SH2, TRACK, VCH>, COST2_NWAVE * 64, 0);
     if (per_cu < 1) per_cu = 1;
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
@@ -1315,8 +1548,8 @@ int launch_cost2_t(r3d_ctx *ctx, const SgmGeom &g, hipStream_t st) {
     const int nSpec = SH2 > 0 ? 3 : 0;
     int *maxc = (int *)ctx->flags.p + 8;
     if (TRACK) R3D_HIP(ctx, hipMemsetAsync(maxc, 0, 4, st));
-    k_cost2<LPC, SH2, TRACK><<<dim3(tiles, nMain + nSpec), COST2_NWAVE * 64, 0, st>>>((const uint2 *)ctx->rec_l.p, (const uint2 *)ctx->rec_r.p, g,
-                                                                                        (int *)ctx->cost.p, (int *)ctx->cspec.p, BAND, nMain, maxc);
+    k_cost2<LPC, SH2, TRACK, VCH><<<dim3(tiles, VCH ? 4 : nMain + nSpec), COST2_NWAVE * 64, 0, st>>>(
+        (const uint2 *)ctx->rec_l.p, (const uint2 *)ctx->rec_r.p, g, (int *)ctx->cost.p, (int *)ctx->cspec.p, BAND, nMain, maxc, (int *)ctx->ltop.p);
     R3D_HIP(ctx, hipGetLastError());
     if (TRACK) {
         // data-dependent half of the exact-int16 envelope: only reached when the static bound cannot prove it
@@ -1328,20 +1561,21 @@ int launch_cost2_t(r3d_ctx *ctx, const SgmGeom &g, hipStream_t st) {
     }
     return R3D_OK;
 }
-template <int LPC>
+template <int LPC, bool VCH>
 int launch_cost2_l(r3d_ctx *ctx, const SgmGeom &g, hipStream_t st) {
     const bool track = (long)(2 * g.SH2 + 1) * (2 * g.SH2 + 1) * (2L * g.ftzero + 63) > 16383;
     switch (g.SH2) {
-        case 0: return launch_cost2_t<LPC, 0, false>(ctx, g, st);
-        case 1: return launch_cost2_t<LPC, 1, false>(ctx, g, st);
-        case 2: return launch_cost2_t<LPC, 2, false>(ctx, g, st);
-        case 3: return track ? launch_cost2_t<LPC, 3, true>(ctx, g, st) : launch_cost2_t<LPC, 3, false>(ctx, g, st);
-        case 4: return track ? launch_cost2_t<LPC, 4, true>(ctx, g, st) : launch_cost2_t<LPC, 4, false>(ctx, g, st);
-        default: return launch_cost2_t<LPC, 5, true>(ctx, g, st);
+        case 0: return launch_cost2_t<LPC, 0, false, VCH>(ctx, g, st);
+        case 1: return launch_cost2_t<LPC, 1, false, VCH>(ctx, g, st);
+        case 2: return launch_cost2_t<LPC, 2, false, VCH>(ctx, g, st);
+        case 3: return track ? launch_cost2_t<LPC, 3, true, VCH>(ctx, g, st) : launch_cost2_t<LPC, 3, false, VCH>(ctx, g, st);
+        case 4: return track ? launch_cost2_t<LPC, 4, true, VCH>(ctx, g, st) : launch_cost2_t<LPC, 4, false, VCH>(ctx, g, st);
+        default: return launch_cost2_t<LPC, 5, true, VCH>(ctx, g, st);
     }
 }
-int launch_cost2(r3d_ctx *ctx, const SgmGeom &g, hipStream_t st) {
-    return g.NP == 1 ? launch_cost2_l<8>(ctx, g, st) : launch_cost2_l<16>(ctx, g, st);
+int launch_cost2(r3d_ctx *ctx, const SgmGeom &g, hipStream_t st, bool vch) {
+    if (vch) return g.NP == 1 ? launch_cost2_l<8, true>(ctx, g, st) : launch_cost2_l<16, true>(ctx, g, st);
+    return g.NP == 1 ? launch_cost2_l<8, false>(ctx, g, st) : launch_cost2_l<16, false>(ctx, g, st);
 }
 
 }  // namespace
@@ -1412,7 +1646,6 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
     if ((rc = r3d_reserve(ctx, ctx->rec_r, npix * 8))) return rc;
     if ((rc = r3d_reserve(ctx, ctx->cost, volBytes))) return rc;
     if ((rc = r3d_reserve(ctx, ctx->cspec, rowBytes * 3 * (g.SH2 > 0 ? g.SH2 : 1)))) return rc;
-    if ((rc = r3d_reserve(ctx, ctx->hsum, volBytes))) return rc;
     if ((rc = r3d_reserve(ctx, ctx->raw, npix * 2))) return rc;
     if ((rc = r3d_reserve(ctx, ctx->mins, npix * 2))) return rc;
     if ((rc = r3d_reserve(ctx, ctx->lrd, npix * 2))) return rc;
@@ -1425,7 +1658,35 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
     k_prefilter<<<dim3((w + 255) / 256, h, 2), 256, 0, st>>>(d_left, d_right, stride, w, h, g.ftzero, (uint2 *)ctx->rec_l.p, (uint2 *)ctx->rec_r.p);
     R3D_HIP(ctx, hipGetLastError());
 
-    static const bool use_v1 = [] { const char *e = getenv("R3D_SGM_IMPL"); return e && !strcmp(e, "v1"); }();
+    // implementation generations kept side by side for A/B measurements: R3D_SGM_IMPL = v1 | v2 | v3 (default)
+    static const int impl = [] { const char *e = getenv("R3D_SGM_IMPL"); return !e ? 3 : !strcmp(e, "v1") ? 1 : !strcmp(e, "v2") ? 2 : 3; }();
+    const bool use_v1 = impl == 1;
+    ctx->last_impl = impl;
+    const float inv_a = 1.0f / (float)(100 - g.uniq);
+    if (impl == 3) {
+        if ((rc = r3d_reserve(ctx, ctx->ltop, volBytes))) return rc;
+        r3d_prof_mark(ctx, "cost_vpath");
+        if ((rc = launch_cost2(ctx, g, st, true))) return rc;
+        r3d_prof_mark(ctx, "hscan_wta");
+        constexpr int K1 = 12, K2 = 6;
+        const int K = g.NP == 1 ? K1 : K2;
+        const bool padded = g.D != 128 * g.NP;
+        const int nwaves = (h + 1) / 2;
+        if ((rc = r3d_reserve(ctx, ctx->ckpt, (size_t)nwaves * (g.W1 / K + 1) * (2 * g.NP + 1) * 64 * 4))) return rc;
+        if ((rc = r3d_reserve(ctx, ctx->hsum, (size_t)h * K * NPW * 4 + 4096))) return rc;   // tail parking only
+        const int *cp = (const int *)ctx->cost.p, *lp = (const int *)ctx->ltop.p;
+        int *tp = (int *)ctx->hsum.p, *kp = (int *)ctx->ckpt.p;
+        int16_t *rp = (int16_t *)ctx->raw.p, *mp = (int16_t *)ctx->mins.p;
+        if (g.NP == 1) {
+            if (padded) k_hscan3<2, 32, K1, true><<<nwaves, 64, 0, st>>>(cp, lp, tp, kp, g, inv_a, rp, mp);
+            else k_hscan3<2, 32, K1, false><<<nwaves, 64, 0, st>>>(cp, lp, tp, kp, g, inv_a, rp, mp);
+        } else {
+            if (padded) k_hscan3<4, 32, K2, true><<<nwaves, 64, 0, st>>>(cp, lp, tp, kp, g, inv_a, rp, mp);
+            else k_hscan3<4, 32, K2, false><<<nwaves, 64, 0, st>>>(cp, lp, tp, kp, g, inv_a, rp, mp);
+        }
+        R3D_HIP(ctx, hipGetLastError());
+    } else {
+    if ((rc = r3d_reserve(ctx, ctx->hsum, volBytes))) return rc;
     if (use_v1) {
         r3d_prof_mark(ctx, "cost");
         const int TX = 16, BAND = 64;
@@ -1446,7 +1707,7 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
         R3D_HIP(ctx, hipGetLastError());
     } else {
         r3d_prof_mark(ctx, "cost");
-        if ((rc = launch_cost2(ctx, g, st))) return rc;
+        if ((rc = launch_cost2(ctx, g, st, false))) return rc;
     }
     r3d_prof_mark(ctx, "hscan");
     if (use_v1) {
@@ -1476,7 +1737,6 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
     {
         constexpr int CPW = 8;
         dim3 grid((g.W1 + CPW - 1) / CPW, 4);
-        const float inv_a = 1.0f / (float)(100 - g.uniq);
         if (!use_v1) {
             if (g.NP == 1) k_vscan2<8><<<dim3((g.W1 + 7) / 8, 4), 64, 0, st>>>((const int *)ctx->cost.p, (const int *)ctx->cspec.p, (const int *)ctx->hsum.p, g, inv_a, (int16_t *)ctx->raw.p, (int16_t *)ctx->mins.p);
             else k_vscan2<16><<<dim3((g.W1 + 3) / 4, 4), 64, 0, st>>>((const int *)ctx->cost.p, (const int *)ctx->cspec.p, (const int *)ctx->hsum.p, g, inv_a, (int16_t *)ctx->raw.p, (int16_t *)ctx->mins.p);
@@ -1484,6 +1744,7 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
         else k_vscan<2, CPW><<<grid, 64, 0, st>>>((const int *)ctx->cost.p, (const int *)ctx->cspec.p, (const int *)ctx->hsum.p, g, (int16_t *)ctx->raw.p, (int16_t *)ctx->mins.p);
         R3D_HIP(ctx, hipGetLastError());
     }
+    }  // impl 1 / 2
     r3d_prof_mark(ctx, "lrcheck");
     k_lrcheck<<<h, 256, (size_t)w * 4, st>>>((const int16_t *)ctx->raw.p, (const int16_t *)ctx->mins.p, g, (int16_t *)ctx->lrd.p);
     R3D_HIP(ctx, hipGetLastError());
