@@ -49,7 +49,7 @@ def stage_case(W, H, D, seed):
     L, R, _ = r3d.synth.stereo_pair(W, H, D, seed=seed)
     m = r3d.StereoSGBM_create(numDisparities=D, mode=2, **KW)
     got = m.compute(L, R)
-    want_h = os.environ.get("R3D_SGM_IMPL", "v3") != "v3"
+    want_h = os.environ.get("R3D_SGM_IMPL", "v2") != "v3"
     st = m.debug_fetch(want_cost=True, want_hsum=want_h, want_raw=True)
     p = so.make_params(numDisparities=D, **KW)
     want, want_raw = so.compute(L, R, p, nthreads=8, return_raw=True)
