@@ -460,17 +460,24 @@ __global__ void __launch_bounds__(COST2_NWAVE * 64) k_cost2(const uint2 *__restr
     for (int j = 0; j < NPL; j++) LT[j] = lane_valid ? 0 : PADPK;
     const int P1pk = pk_dup(g.P1);
 
-    // (a) staging of image row `row` into buffer b
-    auto stage = [&](int row, int b) {
+    // (a) staging of an image row: the raw records are fetched one iteration EARLY into registers (fetch), and turned
+    // into LDS pair words one iteration later (commit), so the global-load latency is never waited for inside a row
+    static_assert(NRR <= NT, "one pair-word record per thread");
+    uint2 pfL = make_uint2(0, 0), pfA = make_uint2(0, 0), pfB = make_uint2(0, 0);
+    auto fetch = [&](int row) {
         const uint2 *lr = recL + (size_t)row * g.W, *rr = recR + (size_t)row * g.W;
-        if (tid < TC) {
-            const int xx = min(max(t0 - SH2 + tid, 0), g.W1 - 1) + g.minX1;
-            sL[b][tid] = lr[xx];
+        if (tid < TC) pfL = lr[min(max(t0 - SH2 + tid, 0), g.W1 - 1) + g.minX1];
+        if (tid < NRR) {
+            const int r = r_base + tid;
+            pfA = rr[min(max(r, 0), g.W - 1)];
+            pfB = rr[min(max(r - 1, 0), g.W - 1)];
         }
-        for (int ri = tid; ri < NRR; ri += NT) {
-            const int r = r_base + ri;
-            const uint2 A = rr[min(max(r, 0), g.W - 1)], B = rr[min(max(r - 1, 0), g.W - 1)];
-            int *o = &sW[b][ri * 6 + (ri >> 4) * 8];
+    };
+    auto commit = [&](int b) {
+        if (tid < TC) sL[b][tid] = pfL;
+        if (tid < NRR) {
+            const uint2 A = pfA, B = pfB;
+            int *o = &sW[b][tid * 6 + (tid >> 4) * 8];
             o[0] = __builtin_amdgcn_perm(B.x, A.x, 0x0c040c00); o[1] = __builtin_amdgcn_perm(B.x, A.x, 0x0c050c01);
             o[2] = __builtin_amdgcn_perm(B.x, A.x, 0x0c060c02); o[3] = __builtin_amdgcn_perm(B.x, A.x, 0x0c070c03);
             o[4] = __builtin_amdgcn_perm(B.y, A.y, 0x0c040c00); o[5] = __builtin_amdgcn_perm(B.y, A.y, 0x0c050c01);
@@ -506,7 +513,9 @@ __global__ void __launch_bounds__(COST2_NWAVE * 64) k_cost2(const uint2 *__restr
     int *optr = obase + (size_t)(t0 - SH2 + cl) * DPW + k * NPL;
     const int tile_x0 = t0 - SH2;
     int cmax = 0;   // TRACK: running maximum of every emitted block cost (exact-arithmetic envelope check on the host)
-    stage(crow(y0 - SH2), 0);
+    fetch(crow(y0 - SH2));
+    commit(0);
+    fetch(crow(y0 - SH2 + 1));
     __syncthreads();
     // iteration t: row e = y0 - SH2 + t enters the window (inputs in buffer t&1, staged one iteration earlier);
     // from t = 2*SH2 on the window is full and output row y = e - SH2 is produced.  One barrier per iteration.
@@ -535,7 +544,8 @@ __global__ void __launch_bounds__(COST2_NWAVE * 64) k_cost2(const uint2 *__restr
             *(int4 *)&sV[b][cl * DPW + (DPW / 2) * (cl & 1) + 4 * k] = make_int4(vs[0], vs[1], vs[2], vs[3]);
             *(int4 *)&sV[b][cl * DPW + (DPW / 2) * ((cl & 1) ^ 1) + 4 * k] = make_int4(vs[4], vs[5], vs[6], vs[7]);
         }
-        if (t + 1 < niter) stage(crow(y0 - SH2 + t + 1), b ^ 1);
+        commit(b ^ 1);                                  // row t+1 (fetched during iteration t-1)
+        fetch(crow(y0 - SH2 + t + 2));                  // row t+2, consumed by the next iteration's commit
         __syncthreads();
         if (outp && is_out) {
             int c[NPL];
@@ -1716,15 +1726,23 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
         if (g.NP == 1) k_hscan<1><<<h, 64, 0, st>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, g);
         else k_hscan<2><<<h, 64, 0, st>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, g);
     } else {
-        // D <= 128: 2 registers x 32 lanes per row (2 rows per wave); D <= 256: 4 x 32
-        constexpr int K1 = 12, K2 = 6;
-        const int K = g.NP == 1 ? K1 : K2;
+        // D <= 128: 4 registers x 16 lanes per row = 4 rows per wave: 612 waves <= 1024 SIMDs, so no SIMD carries two
+        // waves (with 2 rows per wave 1224 waves left 200 SIMDs with double work: makespan 2x the mean);
+        // R3D_HSCAN_ROWS=2 selects the 2-rows-per-wave instantiation for A/B.  D <= 256: 4 x 32 (2 rows per wave).
+        static const bool rows2 = [] { const char *e = getenv("R3D_HSCAN_ROWS"); return e && !strcmp(e, "2"); }();
+        constexpr int K1 = 12, K1b = 8, K2 = 6;
         const bool padded = g.D != 128 * g.NP;
-        const int nwaves = (h + 1) / 2;
-        if ((rc = r3d_reserve(ctx, ctx->ckpt, (size_t)nwaves * (g.W1 / K + 1) * (2 * g.NP + 1) * 64 * 4))) return rc;
+        const bool four = g.NP == 1 && !rows2;
+        const int rpw = four ? 4 : 2, npl = four ? 4 : 2 * g.NP;
+        const int K = four ? K1b : (g.NP == 1 ? K1 : K2);
+        const int nwaves = (h + rpw - 1) / rpw;
+        if ((rc = r3d_reserve(ctx, ctx->ckpt, (size_t)nwaves * (g.W1 / K + 1) * (npl + 1) * 64 * 4))) return rc;
         const int *cp = (const int *)ctx->cost.p;
         int *hp = (int *)ctx->hsum.p, *kp = (int *)ctx->ckpt.p;
-        if (g.NP == 1) {
+        if (four) {
+            if (padded) k_hscan2<4, 16, K1b, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
+            else k_hscan2<4, 16, K1b, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
+        } else if (g.NP == 1) {
             if (padded) k_hscan2<2, 32, K1, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
             else k_hscan2<2, 32, K1, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
         } else {
