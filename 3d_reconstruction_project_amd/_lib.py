@@ -52,6 +52,7 @@ _SIGS = {
     "r3d_event_elapsed_ms": ([_vp, _vp, _vp, ctypes.POINTER(ctypes.c_float)], ctypes.c_int),
     "r3d_sgbm_compute": ([_vp, ctypes.POINTER(SgbmParams), _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp], ctypes.c_int),
     "r3d_sgbm_compute_dev": ([_vp, ctypes.POINTER(SgbmParams), _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp], ctypes.c_int),
+    "r3d_sgbm_compute_batch_dev": ([_vp, ctypes.POINTER(SgbmParams), ctypes.c_int32, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp], ctypes.c_int),
     "r3d_filter_speckles": ([_vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32], ctypes.c_int),
     "r3d_set_profiling": ([_vp, ctypes.c_int], ctypes.c_int),
     "r3d_sgbm_profile": ([_vp, ctypes.POINTER(ctypes.c_float), ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32], ctypes.c_int),

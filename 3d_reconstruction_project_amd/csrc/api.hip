@@ -20,7 +20,7 @@ int r3d_fail(r3d_ctx *ctx, int code, const char *fmt, ...) {
 int r3d_reserve(r3d_ctx *ctx, r3d_buf &b, size_t bytes) {
     if (bytes <= b.cap) return R3D_OK;
     if (b.p) {
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipDeviceSynchronize();   // lanes run on their own streams
         (void)hipFree(b.p);
         b.p = nullptr;
         b.cap = 0;
@@ -87,15 +87,23 @@ void r3d_destroy(r3d_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    r3d_buf *bufs[] = {&ctx->img_l, &ctx->img_r, &ctx->rec_l, &ctx->rec_r, &ctx->cost, &ctx->cspec, &ctx->hsum, &ctx->ltop, &ctx->ckpt,
-                       &ctx->raw, &ctx->mins, &ctx->lrd, &ctx->out, &ctx->flags, &ctx->spk_l, &ctx->spk_c};
+    (void)hipDeviceSynchronize();
+    r3d_buf *bufs[] = {&ctx->img_l, &ctx->img_r, &ctx->out};
     for (r3d_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
+    for (r3d_sgm_ws &ws : ctx->ws) {
+        r3d_buf *wb[] = {&ws.rec_l, &ws.rec_r, &ws.cost, &ws.cspec, &ws.hsum, &ws.ltop, &ws.ckpt, &ws.raw, &ws.mins, &ws.lrd, &ws.flags, &ws.spk_l, &ws.spk_c};
+        for (r3d_buf *b : wb)
+            if (b->p) (void)hipFree(b->p);
+        if (ws.ev_created)
+            for (auto &ps : ws.prof)
+                for (int i = 0; i <= R3D_MAX_PROF; i++) (void)hipEventDestroy(ps.ev[i]);
+        if (ws.stream) (void)hipStreamDestroy(ws.stream);
+        if (ws.done) (void)hipEventDestroy(ws.done);
+    }
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     for (r3d_buf &b : ctx->cloud_bufs)
         if (b.p) (void)hipFree(b.p);
-    if (ctx->ev_created)
-        for (auto &ps : ctx->prof)
-            for (int i = 0; i <= R3D_MAX_PROF; i++) (void)hipEventDestroy(ps.ev[i]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -182,8 +190,9 @@ int r3d_set_profiling(r3d_ctx *ctx, int enabled) {
 
 int r3d_sgbm_profile(r3d_ctx *ctx, float *ms, int32_t max_slots, char *names, int32_t names_bytes) {
     if (!ctx) return R3D_E_BADARG;
-    for (auto &ps : ctx->prof)
-        if (ps.pending) r3d_prof_harvest(ctx, ps);
+    for (r3d_sgm_ws &ws : ctx->ws)
+        for (auto &ps : ws.prof)
+            if (ps.pending) r3d_prof_harvest(ctx, ps);
     int n = ctx->n_acc < max_slots ? ctx->n_acc : max_slots;
     size_t off = 0;
     for (int i = 0; i < n; i++) {
@@ -200,7 +209,36 @@ int r3d_sgbm_profile(r3d_ctx *ctx, float *ms, int32_t max_slots, char *names, in
 int r3d_sgbm_compute_dev(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, const uint8_t *d_right, int32_t w,
                          int32_t h, int32_t stride, int16_t *d_disp) {
     if (!ctx) return R3D_E_BADARG;
-    return r3d_sgm_run(ctx, p, d_left, d_right, w, h, stride, d_disp);
+    return r3d_sgm_run(ctx, 0, ctx->stream, p, d_left, d_right, w, h, stride, d_disp);
+}
+
+int r3d_sgbm_compute_batch_dev(r3d_ctx *ctx, const r3d_sgbm_params *p, int32_t n, const uint8_t *const *d_left,
+                               const uint8_t *const *d_right, int32_t w, int32_t h, int32_t stride, int16_t *const *d_disp) {
+    if (!ctx) return R3D_E_BADARG;
+    if (n < 0 || (n > 0 && (!d_left || !d_right || !d_disp))) return r3d_fail(ctx, R3D_E_BADARG, "sgbm batch: bad argument");
+    if (n == 0) return R3D_OK;
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    const int lanes = n < R3D_SGM_LANES ? n : R3D_SGM_LANES;
+    if (!ctx->fork_ev) R3D_HIP(ctx, hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
+    for (int l = 0; l < lanes; l++) {
+        r3d_sgm_ws &ws = ctx->ws[l];
+        if (!ws.stream) R3D_HIP(ctx, hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking));
+        if (!ws.done) R3D_HIP(ctx, hipEventCreateWithFlags(&ws.done, hipEventDisableTiming));
+    }
+    // fork: every lane starts after whatever is already queued on the context stream
+    R3D_HIP(ctx, hipEventRecord(ctx->fork_ev, ctx->stream));
+    for (int l = 0; l < lanes; l++) R3D_HIP(ctx, hipStreamWaitEvent(ctx->ws[l].stream, ctx->fork_ev, 0));
+    int rc = R3D_OK;
+    for (int i = 0; i < n && rc == R3D_OK; i++) {
+        const int l = i % lanes;
+        rc = r3d_sgm_run(ctx, l, ctx->ws[l].stream, p, d_left[i], d_right[i], w, h, stride, d_disp[i]);
+    }
+    // join: the context stream continues after every lane has drained
+    for (int l = 0; l < lanes; l++) {
+        R3D_HIP(ctx, hipEventRecord(ctx->ws[l].done, ctx->ws[l].stream));
+        R3D_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ws[l].done, 0));
+    }
+    return rc;
 }
 
 int r3d_sgbm_compute(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *left, const uint8_t *right, int32_t w, int32_t h,
@@ -214,7 +252,7 @@ int r3d_sgbm_compute(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *left
     if ((rc = r3d_reserve(ctx, ctx->img_l, ib)) || (rc = r3d_reserve(ctx, ctx->img_r, ib)) || (rc = r3d_reserve(ctx, ctx->out, ob))) return rc;
     R3D_HIP(ctx, hipMemcpyAsync(ctx->img_l.p, left, ib, hipMemcpyHostToDevice, ctx->stream));
     R3D_HIP(ctx, hipMemcpyAsync(ctx->img_r.p, right, ib, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = r3d_sgm_run(ctx, p, (const uint8_t *)ctx->img_l.p, (const uint8_t *)ctx->img_r.p, w, h, stride, (int16_t *)ctx->out.p))) return rc;
+    if ((rc = r3d_sgm_run(ctx, 0, ctx->stream, p, (const uint8_t *)ctx->img_l.p, (const uint8_t *)ctx->img_r.p, w, h, stride, (int16_t *)ctx->out.p))) return rc;
     R3D_HIP(ctx, hipMemcpyAsync(disp, ctx->out.p, ob, hipMemcpyDeviceToHost, ctx->stream));
     R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return R3D_OK;
@@ -228,7 +266,7 @@ int r3d_filter_speckles(r3d_ctx *ctx, int16_t *img, int32_t w, int32_t h, int32_
     int rc;
     if ((rc = r3d_reserve(ctx, ctx->out, bytes))) return rc;
     R3D_HIP(ctx, hipMemcpyAsync(ctx->out.p, img, bytes, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = r3d_speckle_run(ctx, (int16_t *)ctx->out.p, w, h, new_val, max_speckle_size, max_diff))) return rc;
+    if ((rc = r3d_speckle_run(ctx, ctx->ws[0], ctx->stream, (int16_t *)ctx->out.p, w, h, new_val, max_speckle_size, max_diff))) return rc;
     R3D_HIP(ctx, hipMemcpyAsync(img, ctx->out.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return R3D_OK;
@@ -239,12 +277,12 @@ int r3d_sgbm_debug_fetch(r3d_ctx *ctx, int16_t *cost, int16_t *hsum, int16_t *ra
     if (ctx->last_w == 0) return r3d_fail(ctx, R3D_E_BADARG, "debug_fetch: no sgbm call yet");
     R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const size_t vol = (size_t)ctx->last_h * ctx->last_w1 * ctx->last_dp * 2;
-    if (cost) R3D_HIP(ctx, hipMemcpy(cost, ctx->cost.p, vol, hipMemcpyDeviceToHost));
+    if (cost) R3D_HIP(ctx, hipMemcpy(cost, ctx->ws[0].cost.p, vol, hipMemcpyDeviceToHost));
     if (hsum) {
         if (ctx->last_impl == 3) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "debug_fetch: the v3 pipeline never materialises L_left + L_right (set R3D_SGM_IMPL=v2)");
-        R3D_HIP(ctx, hipMemcpy(hsum, ctx->hsum.p, vol, hipMemcpyDeviceToHost));
+        R3D_HIP(ctx, hipMemcpy(hsum, ctx->ws[0].hsum.p, vol, hipMemcpyDeviceToHost));
     }
-    if (raw) R3D_HIP(ctx, hipMemcpy(raw, ctx->lrd.p, (size_t)ctx->last_w * ctx->last_h * 2, hipMemcpyDeviceToHost));
+    if (raw) R3D_HIP(ctx, hipMemcpy(raw, ctx->ws[0].lrd.p, (size_t)ctx->last_w * ctx->last_h * 2, hipMemcpyDeviceToHost));
     return R3D_OK;
 }
 

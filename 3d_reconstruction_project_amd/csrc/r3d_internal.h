@@ -23,6 +23,20 @@ struct r3d_prof_set {
     bool pending = false;
 };
 
+#define R3D_SGM_LANES 3
+
+// one SGM pipeline lane: its own grow-only workspace, stream and profiling event ring.  Single-map calls use lane 0 on
+// the context stream; r3d_sgbm_compute_batch_dev spreads maps over the lanes so that kernels with complementary
+// bottlenecks (cost: VALU + writes, hscan: HBM, vscan: mixed) of consecutive maps overlap.
+struct r3d_sgm_ws {
+    r3d_buf rec_l, rec_r, cost, cspec, hsum, ltop, ckpt, raw, mins, lrd, flags, spk_l, spk_c;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    r3d_prof_set prof[R3D_PROF_SETS];
+    int prof_cur = 0;
+    bool ev_created = false;
+};
+
 struct r3d_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -30,13 +44,12 @@ struct r3d_ctx {
     std::string err;
     bool profiling = false;
     // grow-only workspace
-    r3d_buf img_l, img_r, rec_l, rec_r, cost, cspec, hsum, ltop, ckpt, raw, mins, lrd, out, flags, spk_l, spk_c;
+    r3d_buf img_l, img_r, out;
+    r3d_sgm_ws ws[R3D_SGM_LANES];
+    hipEvent_t fork_ev = nullptr;
     // geometry of the last sgbm call (for debug fetch)
     int last_w = 0, last_h = 0, last_w1 = 0, last_dp = 0, last_impl = 0;
-    // profiling: ring of event sets so that harvesting never stalls the stream; sums accumulate per kernel name
-    r3d_prof_set prof[R3D_PROF_SETS];
-    int prof_cur = 0;
-    bool ev_created = false;
+    // profiling sums accumulate per kernel name over all lanes
     const char *acc_name[R3D_MAX_PROF] = {};
     double acc_ms[R3D_MAX_PROF] = {};
     int acc_cnt[R3D_MAX_PROF] = {};
@@ -58,36 +71,36 @@ int r3d_reserve(r3d_ctx *ctx, r3d_buf &b, size_t bytes);
 
 // profiling helpers: record an event before each named kernel when ctx->profiling
 void r3d_prof_harvest(r3d_ctx *ctx, r3d_prof_set &ps);
-static inline void r3d_prof_begin(r3d_ctx *ctx) {
+static inline void r3d_prof_begin(r3d_ctx *ctx, r3d_sgm_ws &ws) {
     if (!ctx->profiling) return;
-    if (!ctx->ev_created) {
-        for (auto &ps : ctx->prof)
+    if (!ws.ev_created) {
+        for (auto &ps : ws.prof)
             for (int i = 0; i <= R3D_MAX_PROF; i++) (void)hipEventCreate(&ps.ev[i]);
-        ctx->ev_created = true;
+        ws.ev_created = true;
     }
-    ctx->prof_cur = (ctx->prof_cur + 1) % R3D_PROF_SETS;
-    r3d_prof_set &ps = ctx->prof[ctx->prof_cur];
+    ws.prof_cur = (ws.prof_cur + 1) % R3D_PROF_SETS;
+    r3d_prof_set &ps = ws.prof[ws.prof_cur];
     if (ps.pending) r3d_prof_harvest(ctx, ps);
     ps.n = 0;
 }
-static inline void r3d_prof_mark(r3d_ctx *ctx, const char *name) {
+static inline void r3d_prof_mark(r3d_ctx *ctx, r3d_sgm_ws &ws, hipStream_t st, const char *name) {
     if (!ctx->profiling) return;
-    r3d_prof_set &ps = ctx->prof[ctx->prof_cur];
+    r3d_prof_set &ps = ws.prof[ws.prof_cur];
     if (ps.n >= R3D_MAX_PROF) return;
-    (void)hipEventRecord(ps.ev[ps.n], ctx->stream);
+    (void)hipEventRecord(ps.ev[ps.n], st);
     ps.name[ps.n] = name;
     ps.n++;
 }
-static inline void r3d_prof_end(r3d_ctx *ctx) {
+static inline void r3d_prof_end(r3d_ctx *ctx, r3d_sgm_ws &ws, hipStream_t st) {
     if (!ctx->profiling) return;
-    r3d_prof_set &ps = ctx->prof[ctx->prof_cur];
-    (void)hipEventRecord(ps.ev[ps.n], ctx->stream);
+    r3d_prof_set &ps = ws.prof[ws.prof_cur];
+    (void)hipEventRecord(ps.ev[ps.n], st);
     ps.pending = true;
 }
 
 // sgm.hip
-int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, const uint8_t *d_right, int w, int h,
-                int stride, int16_t *d_disp);
+int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p, const uint8_t *d_left, const uint8_t *d_right,
+                int w, int h, int stride, int16_t *d_disp);
 int r3d_selftest_run(r3d_ctx *ctx);
-int r3d_speckle_run(r3d_ctx *ctx, int16_t *d_img, int w, int h, int newVal, int maxSize, int maxDiff);
+int r3d_speckle_run(r3d_ctx *ctx, r3d_sgm_ws &ws, hipStream_t st, int16_t *d_img, int w, int h, int newVal, int maxSize, int maxDiff);
 int r3d_streambench_run(r3d_ctx *ctx, int mode, int rows, size_t row_bytes, int write, int delay, int reps, float *ms);

@@ -1539,7 +1539,7 @@ int derive_geom(r3d_ctx *ctx, const r3d_sgbm_params *p, int w, int h, SgmGeom &g
 }
 
 template <int LPC, int SH2, bool TRACK, bool VCH>
-int launch_cost2_t(r3d_ctx *ctx, const SgmGeom &g, hipStream_t st) {
+int launch_cost2_t(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st) {
     constexpr int CW = 64 / LPC, TC = COST2_NWAVE * CW, TO = TC - 2 * SH2;
     static_assert(TO > 0, "tile too small for this block size");
     const int tiles = (g.W1 + TO - 1) / TO;
@@ -1556,10 +1556,10 @@ int launch_cost2_t(r3d_ctx *ctx, const SgmGeom &g, hipStream_t st) {
     if (BAND < 16) BAND = 16;
     const int nMain = (g.H + BAND - 1) / BAND;
     const int nSpec = SH2 > 0 ? 3 : 0;
-    int *maxc = (int *)ctx->flags.p + 8;
+    int *maxc = (int *)ws.flags.p + 8;
     if (TRACK) R3D_HIP(ctx, hipMemsetAsync(maxc, 0, 4, st));
     k_cost2<LPC, SH2, TRACK, VCH><<<dim3(tiles, VCH ? 4 : nMain + nSpec), COST2_NWAVE * 64, 0, st>>>(
-        (const uint2 *)ctx->rec_l.p, (const uint2 *)ctx->rec_r.p, g, (int *)ctx->cost.p, (int *)ctx->cspec.p, BAND, nMain, maxc, (int *)ctx->ltop.p);
+        (const uint2 *)ws.rec_l.p, (const uint2 *)ws.rec_r.p, g, (int *)ws.cost.p, (int *)ws.cspec.p, BAND, nMain, maxc, (int *)ws.ltop.p);
     R3D_HIP(ctx, hipGetLastError());
     if (TRACK) {
         // data-dependent half of the exact-int16 envelope: only reached when the static bound cannot prove it
@@ -1572,20 +1572,20 @@ int launch_cost2_t(r3d_ctx *ctx, const SgmGeom &g, hipStream_t st) {
     return R3D_OK;
 }
 template <int LPC, bool VCH>
-int launch_cost2_l(r3d_ctx *ctx, const SgmGeom &g, hipStream_t st) {
+int launch_cost2_l(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st) {
     const bool track = (long)(2 * g.SH2 + 1) * (2 * g.SH2 + 1) * (2L * g.ftzero + 63) > 16383;
     switch (g.SH2) {
-        case 0: return launch_cost2_t<LPC, 0, false, VCH>(ctx, g, st);
-        case 1: return launch_cost2_t<LPC, 1, false, VCH>(ctx, g, st);
-        case 2: return launch_cost2_t<LPC, 2, false, VCH>(ctx, g, st);
-        case 3: return track ? launch_cost2_t<LPC, 3, true, VCH>(ctx, g, st) : launch_cost2_t<LPC, 3, false, VCH>(ctx, g, st);
-        case 4: return track ? launch_cost2_t<LPC, 4, true, VCH>(ctx, g, st) : launch_cost2_t<LPC, 4, false, VCH>(ctx, g, st);
-        default: return launch_cost2_t<LPC, 5, true, VCH>(ctx, g, st);
+        case 0: return launch_cost2_t<LPC, 0, false, VCH>(ctx, ws, g, st);
+        case 1: return launch_cost2_t<LPC, 1, false, VCH>(ctx, ws, g, st);
+        case 2: return launch_cost2_t<LPC, 2, false, VCH>(ctx, ws, g, st);
+        case 3: return track ? launch_cost2_t<LPC, 3, true, VCH>(ctx, ws, g, st) : launch_cost2_t<LPC, 3, false, VCH>(ctx, ws, g, st);
+        case 4: return track ? launch_cost2_t<LPC, 4, true, VCH>(ctx, ws, g, st) : launch_cost2_t<LPC, 4, false, VCH>(ctx, ws, g, st);
+        default: return launch_cost2_t<LPC, 5, true, VCH>(ctx, ws, g, st);
     }
 }
-int launch_cost2(r3d_ctx *ctx, const SgmGeom &g, hipStream_t st, bool vch) {
-    if (vch) return g.NP == 1 ? launch_cost2_l<8, true>(ctx, g, st) : launch_cost2_l<16, true>(ctx, g, st);
-    return g.NP == 1 ? launch_cost2_l<8, false>(ctx, g, st) : launch_cost2_l<16, false>(ctx, g, st);
+int launch_cost2(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st, bool vch) {
+    if (vch) return g.NP == 1 ? launch_cost2_l<8, true>(ctx, ws, g, st) : launch_cost2_l<16, true>(ctx, ws, g, st);
+    return g.NP == 1 ? launch_cost2_l<8, false>(ctx, ws, g, st) : launch_cost2_l<16, false>(ctx, ws, g, st);
 }
 
 }  // namespace
@@ -1594,14 +1594,14 @@ int r3d_streambench_run(r3d_ctx *ctx, int mode, int rows, size_t row_bytes, int 
     R3D_HIP(ctx, hipSetDevice(ctx->device));
     const size_t row_words = row_bytes / 4, bytes = (size_t)rows * row_bytes;
     int rc;
-    if ((rc = r3d_reserve(ctx, ctx->cost, bytes)) || (rc = r3d_reserve(ctx, ctx->hsum, bytes))) return rc;
+    if ((rc = r3d_reserve(ctx, ctx->ws[0].cost, bytes)) || (rc = r3d_reserve(ctx, ctx->ws[0].hsum, bytes))) return rc;
     hipEvent_t a, b;
     R3D_HIP(ctx, hipEventCreate(&a));
     R3D_HIP(ctx, hipEventCreate(&b));
     for (int i = 0; i < reps + 1; i++) {
         if (i == 1) R3D_HIP(ctx, hipEventRecord(a, ctx->stream));
-        if (mode == 0) k_streambench<0><<<rows, 64, 0, ctx->stream>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, row_words, write, delay);
-        else k_streambench<1><<<rows, 64, 0, ctx->stream>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, row_words, write, delay);
+        if (mode == 0) k_streambench<0><<<rows, 64, 0, ctx->stream>>>((const int *)ctx->ws[0].cost.p, (int *)ctx->ws[0].hsum.p, row_words, write, delay);
+        else k_streambench<1><<<rows, 64, 0, ctx->stream>>>((const int *)ctx->ws[0].cost.p, (int *)ctx->ws[0].hsum.p, row_words, write, delay);
     }
     R3D_HIP(ctx, hipEventRecord(b, ctx->stream));
     R3D_HIP(ctx, hipEventSynchronize(b));
@@ -1612,36 +1612,37 @@ int r3d_streambench_run(r3d_ctx *ctx, int mode, int rows, size_t row_bytes, int 
     return R3D_OK;
 }
 
-int r3d_speckle_run(r3d_ctx *ctx, int16_t *d_img, int w, int h, int newVal, int maxSize, int maxDiff) {
+int r3d_speckle_run(r3d_ctx *ctx, r3d_sgm_ws &ws, hipStream_t st, int16_t *d_img, int w, int h, int newVal, int maxSize, int maxDiff) {
     const size_t n = (size_t)w * h;
     if (n > 0x7fffffff) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "filterSpeckles: image too large");
     int rc;
-    if ((rc = r3d_reserve(ctx, ctx->spk_l, n * 4)) || (rc = r3d_reserve(ctx, ctx->spk_c, n * 4))) return rc;
-    int *L = (int *)ctx->spk_l.p, *C = (int *)ctx->spk_c.p;
+    if ((rc = r3d_reserve(ctx, ws.spk_l, n * 4)) || (rc = r3d_reserve(ctx, ws.spk_c, n * 4))) return rc;
+    int *L = (int *)ws.spk_l.p, *C = (int *)ws.spk_c.p;
     const int nb = (int)((n + 255) / 256);
-    k_spk_init<<<nb, 256, 0, ctx->stream>>>(d_img, (int)n, newVal, L, C);
-    k_spk_merge<<<dim3((w + 255) / 256, h), 256, 0, ctx->stream>>>(d_img, w, h, newVal, maxDiff, L);
-    k_spk_count<<<nb, 256, 0, ctx->stream>>>((int)n, L, C);
-    k_spk_apply<<<nb, 256, 0, ctx->stream>>>(d_img, (int)n, newVal, maxSize, L, C);
+    k_spk_init<<<nb, 256, 0, st>>>(d_img, (int)n, newVal, L, C);
+    k_spk_merge<<<dim3((w + 255) / 256, h), 256, 0, st>>>(d_img, w, h, newVal, maxDiff, L);
+    k_spk_count<<<nb, 256, 0, st>>>((int)n, L, C);
+    k_spk_apply<<<nb, 256, 0, st>>>(d_img, (int)n, newVal, maxSize, L, C);
     R3D_HIP(ctx, hipGetLastError());
     return R3D_OK;
 }
 
 int r3d_selftest_run(r3d_ctx *ctx) {
     R3D_HIP(ctx, hipSetDevice(ctx->device));
-    if (int rc = r3d_reserve(ctx, ctx->flags, 256)) return rc;
-    R3D_HIP(ctx, hipMemsetAsync(ctx->flags.p, 0, 4, ctx->stream));
-    k_selftest<<<1, 64, 0, ctx->stream>>>((int *)ctx->flags.p);
+    if (int rc = r3d_reserve(ctx, ctx->ws[0].flags, 256)) return rc;
+    R3D_HIP(ctx, hipMemsetAsync(ctx->ws[0].flags.p, 0, 4, ctx->stream));
+    k_selftest<<<1, 64, 0, ctx->stream>>>((int *)ctx->ws[0].flags.p);
     R3D_HIP(ctx, hipGetLastError());
     int bad = -1;
-    R3D_HIP(ctx, hipMemcpyAsync(&bad, ctx->flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipMemcpyAsync(&bad, ctx->ws[0].flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (bad != 0) return r3d_fail(ctx, R3D_E_HIP, "selftest: cross-lane primitive mismatch, mask=0x%x", bad);
     return R3D_OK;
 }
 
-int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, const uint8_t *d_right, int w, int h,
-                int stride, int16_t *d_disp) {
+int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p, const uint8_t *d_left, const uint8_t *d_right,
+                int w, int h, int stride, int16_t *d_disp) {
+    r3d_sgm_ws &ws = ctx->ws[lane];
     SgmGeom g;
     if (int rc = derive_geom(ctx, p, w, h, g)) return rc;
     if (!d_left || !d_right || !d_disp) return r3d_fail(ctx, R3D_E_BADARG, "sgbm: null image pointer");
@@ -1652,20 +1653,19 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
     const size_t rowBytes = (size_t)g.W1 * NPW * 4;
     const size_t volBytes = rowBytes * h;
     int rc;
-    if ((rc = r3d_reserve(ctx, ctx->rec_l, npix * 8))) return rc;
-    if ((rc = r3d_reserve(ctx, ctx->rec_r, npix * 8))) return rc;
-    if ((rc = r3d_reserve(ctx, ctx->cost, volBytes))) return rc;
-    if ((rc = r3d_reserve(ctx, ctx->cspec, rowBytes * 3 * (g.SH2 > 0 ? g.SH2 : 1)))) return rc;
-    if ((rc = r3d_reserve(ctx, ctx->raw, npix * 2))) return rc;
-    if ((rc = r3d_reserve(ctx, ctx->mins, npix * 2))) return rc;
-    if ((rc = r3d_reserve(ctx, ctx->lrd, npix * 2))) return rc;
+    if ((rc = r3d_reserve(ctx, ws.rec_l, npix * 8))) return rc;
+    if ((rc = r3d_reserve(ctx, ws.rec_r, npix * 8))) return rc;
+    if ((rc = r3d_reserve(ctx, ws.cost, volBytes))) return rc;
+    if ((rc = r3d_reserve(ctx, ws.cspec, rowBytes * 3 * (g.SH2 > 0 ? g.SH2 : 1)))) return rc;
+    if ((rc = r3d_reserve(ctx, ws.raw, npix * 2))) return rc;
+    if ((rc = r3d_reserve(ctx, ws.mins, npix * 2))) return rc;
+    if ((rc = r3d_reserve(ctx, ws.lrd, npix * 2))) return rc;
     ctx->last_w = w; ctx->last_h = h; ctx->last_w1 = g.W1; ctx->last_dp = NPW * 2;
-    hipStream_t st = ctx->stream;
-    if ((rc = r3d_reserve(ctx, ctx->flags, 256))) return rc;
-    r3d_prof_begin(ctx);
+    if ((rc = r3d_reserve(ctx, ws.flags, 256))) return rc;
+    r3d_prof_begin(ctx, ws);
 
-    r3d_prof_mark(ctx, "prefilter");
-    k_prefilter<<<dim3((w + 255) / 256, h, 2), 256, 0, st>>>(d_left, d_right, stride, w, h, g.ftzero, (uint2 *)ctx->rec_l.p, (uint2 *)ctx->rec_r.p);
+    r3d_prof_mark(ctx, ws, st, "prefilter");
+    k_prefilter<<<dim3((w + 255) / 256, h, 2), 256, 0, st>>>(d_left, d_right, stride, w, h, g.ftzero, (uint2 *)ws.rec_l.p, (uint2 *)ws.rec_r.p);
     R3D_HIP(ctx, hipGetLastError());
 
     // implementation generations kept side by side for A/B measurements: R3D_SGM_IMPL = v1 | v2 (default) | v3.
@@ -1676,19 +1676,19 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
     ctx->last_impl = impl;
     const float inv_a = 1.0f / (float)(100 - g.uniq);
     if (impl == 3) {
-        if ((rc = r3d_reserve(ctx, ctx->ltop, volBytes))) return rc;
-        r3d_prof_mark(ctx, "cost_vpath");
-        if ((rc = launch_cost2(ctx, g, st, true))) return rc;
-        r3d_prof_mark(ctx, "hscan_wta");
+        if ((rc = r3d_reserve(ctx, ws.ltop, volBytes))) return rc;
+        r3d_prof_mark(ctx, ws, st, "cost_vpath");
+        if ((rc = launch_cost2(ctx, ws, g, st, true))) return rc;
+        r3d_prof_mark(ctx, ws, st, "hscan_wta");
         constexpr int K1 = 12, K2 = 6;
         const int K = g.NP == 1 ? K1 : K2;
         const bool padded = g.D != 128 * g.NP;
         const int nwaves = (h + 1) / 2;
-        if ((rc = r3d_reserve(ctx, ctx->ckpt, (size_t)nwaves * (g.W1 / K + 1) * (2 * g.NP + 1) * 64 * 4))) return rc;
-        if ((rc = r3d_reserve(ctx, ctx->hsum, (size_t)h * K * NPW * 4 + 4096))) return rc;   // tail parking only
-        const int *cp = (const int *)ctx->cost.p, *lp = (const int *)ctx->ltop.p;
-        int *tp = (int *)ctx->hsum.p, *kp = (int *)ctx->ckpt.p;
-        int16_t *rp = (int16_t *)ctx->raw.p, *mp = (int16_t *)ctx->mins.p;
+        if ((rc = r3d_reserve(ctx, ws.ckpt, (size_t)nwaves * (g.W1 / K + 1) * (2 * g.NP + 1) * 64 * 4))) return rc;
+        if ((rc = r3d_reserve(ctx, ws.hsum, (size_t)h * K * NPW * 4 + 4096))) return rc;   // tail parking only
+        const int *cp = (const int *)ws.cost.p, *lp = (const int *)ws.ltop.p;
+        int *tp = (int *)ws.hsum.p, *kp = (int *)ws.ckpt.p;
+        int16_t *rp = (int16_t *)ws.raw.p, *mp = (int16_t *)ws.mins.p;
         if (g.NP == 1) {
             if (padded) k_hscan3<2, 32, K1, true><<<nwaves, 64, 0, st>>>(cp, lp, tp, kp, g, inv_a, rp, mp);
             else k_hscan3<2, 32, K1, false><<<nwaves, 64, 0, st>>>(cp, lp, tp, kp, g, inv_a, rp, mp);
@@ -1698,9 +1698,9 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
         }
         R3D_HIP(ctx, hipGetLastError());
     } else {
-    if ((rc = r3d_reserve(ctx, ctx->hsum, volBytes))) return rc;
+    if ((rc = r3d_reserve(ctx, ws.hsum, volBytes))) return rc;
     if (use_v1) {
-        r3d_prof_mark(ctx, "cost");
+        r3d_prof_mark(ctx, ws, st, "cost");
         const int TX = 16, BAND = 64;
         int RING = 8;
         while (RING < 2 * g.SW2 + 2) RING *= 2;
@@ -1711,20 +1711,20 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
         dim3 grid((g.W1 + TX - 1) / TX, nMain + nSpec);
         if (g.NP == 1) {
             R3D_HIP(ctx, hipFuncSetAttribute((const void *)k_cost<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_cost<1><<<grid, COST_NW * 64, lds, st>>>((const uint2 *)ctx->rec_l.p, (const uint2 *)ctx->rec_r.p, g, (int *)ctx->cost.p, (int *)ctx->cspec.p, TX, BAND, nMain, RING);
+            k_cost<1><<<grid, COST_NW * 64, lds, st>>>((const uint2 *)ws.rec_l.p, (const uint2 *)ws.rec_r.p, g, (int *)ws.cost.p, (int *)ws.cspec.p, TX, BAND, nMain, RING);
         } else {
             R3D_HIP(ctx, hipFuncSetAttribute((const void *)k_cost<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_cost<2><<<grid, COST_NW * 64, lds, st>>>((const uint2 *)ctx->rec_l.p, (const uint2 *)ctx->rec_r.p, g, (int *)ctx->cost.p, (int *)ctx->cspec.p, TX, BAND, nMain, RING);
+            k_cost<2><<<grid, COST_NW * 64, lds, st>>>((const uint2 *)ws.rec_l.p, (const uint2 *)ws.rec_r.p, g, (int *)ws.cost.p, (int *)ws.cspec.p, TX, BAND, nMain, RING);
         }
         R3D_HIP(ctx, hipGetLastError());
     } else {
-        r3d_prof_mark(ctx, "cost");
-        if ((rc = launch_cost2(ctx, g, st, false))) return rc;
+        r3d_prof_mark(ctx, ws, st, "cost");
+        if ((rc = launch_cost2(ctx, ws, g, st, false))) return rc;
     }
-    r3d_prof_mark(ctx, "hscan");
+    r3d_prof_mark(ctx, ws, st, "hscan");
     if (use_v1) {
-        if (g.NP == 1) k_hscan<1><<<h, 64, 0, st>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, g);
-        else k_hscan<2><<<h, 64, 0, st>>>((const int *)ctx->cost.p, (int *)ctx->hsum.p, g);
+        if (g.NP == 1) k_hscan<1><<<h, 64, 0, st>>>((const int *)ws.cost.p, (int *)ws.hsum.p, g);
+        else k_hscan<2><<<h, 64, 0, st>>>((const int *)ws.cost.p, (int *)ws.hsum.p, g);
     } else {
         // D <= 128: 4 registers x 16 lanes per row = 4 rows per wave: 612 waves <= 1024 SIMDs, so no SIMD carries two
         // waves (with 2 rows per wave 1224 waves left 200 SIMDs with double work: makespan 2x the mean);
@@ -1736,9 +1736,9 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
         const int rpw = four ? 4 : 2, npl = four ? 4 : 2 * g.NP;
         const int K = four ? K1b : (g.NP == 1 ? K1 : K2);
         const int nwaves = (h + rpw - 1) / rpw;
-        if ((rc = r3d_reserve(ctx, ctx->ckpt, (size_t)nwaves * (g.W1 / K + 1) * (npl + 1) * 64 * 4))) return rc;
-        const int *cp = (const int *)ctx->cost.p;
-        int *hp = (int *)ctx->hsum.p, *kp = (int *)ctx->ckpt.p;
+        if ((rc = r3d_reserve(ctx, ws.ckpt, (size_t)nwaves * (g.W1 / K + 1) * (npl + 1) * 64 * 4))) return rc;
+        const int *cp = (const int *)ws.cost.p;
+        int *hp = (int *)ws.hsum.p, *kp = (int *)ws.ckpt.p;
         if (four) {
             if (padded) k_hscan2<4, 16, K1b, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
             else k_hscan2<4, 16, K1b, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
@@ -1752,29 +1752,29 @@ int r3d_sgm_run(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, c
     }
     R3D_HIP(ctx, hipGetLastError());
 
-    r3d_prof_mark(ctx, "vscan_wta");
+    r3d_prof_mark(ctx, ws, st, "vscan_wta");
     // raw must read INVALID wherever the scan does not write (columns outside [minX1, maxX1))
     {
         constexpr int CPW = 8;
         dim3 grid((g.W1 + CPW - 1) / CPW, 4);
         if (!use_v1) {
-            if (g.NP == 1) k_vscan2<8><<<dim3((g.W1 + 7) / 8, 4), 64, 0, st>>>((const int *)ctx->cost.p, (const int *)ctx->cspec.p, (const int *)ctx->hsum.p, g, inv_a, (int16_t *)ctx->raw.p, (int16_t *)ctx->mins.p);
-            else k_vscan2<16><<<dim3((g.W1 + 3) / 4, 4), 64, 0, st>>>((const int *)ctx->cost.p, (const int *)ctx->cspec.p, (const int *)ctx->hsum.p, g, inv_a, (int16_t *)ctx->raw.p, (int16_t *)ctx->mins.p);
-        } else if (g.NP == 1) k_vscan<1, CPW><<<grid, 64, 0, st>>>((const int *)ctx->cost.p, (const int *)ctx->cspec.p, (const int *)ctx->hsum.p, g, (int16_t *)ctx->raw.p, (int16_t *)ctx->mins.p);
-        else k_vscan<2, CPW><<<grid, 64, 0, st>>>((const int *)ctx->cost.p, (const int *)ctx->cspec.p, (const int *)ctx->hsum.p, g, (int16_t *)ctx->raw.p, (int16_t *)ctx->mins.p);
+            if (g.NP == 1) k_vscan2<8><<<dim3((g.W1 + 7) / 8, 4), 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, inv_a, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
+            else k_vscan2<16><<<dim3((g.W1 + 3) / 4, 4), 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, inv_a, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
+        } else if (g.NP == 1) k_vscan<1, CPW><<<grid, 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
+        else k_vscan<2, CPW><<<grid, 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
         R3D_HIP(ctx, hipGetLastError());
     }
     }  // impl 1 / 2
-    r3d_prof_mark(ctx, "lrcheck");
-    k_lrcheck<<<h, 256, (size_t)w * 4, st>>>((const int16_t *)ctx->raw.p, (const int16_t *)ctx->mins.p, g, (int16_t *)ctx->lrd.p);
+    r3d_prof_mark(ctx, ws, st, "lrcheck");
+    k_lrcheck<<<h, 256, (size_t)w * 4, st>>>((const int16_t *)ws.raw.p, (const int16_t *)ws.mins.p, g, (int16_t *)ws.lrd.p);
     R3D_HIP(ctx, hipGetLastError());
-    r3d_prof_mark(ctx, "median3");
-    k_median3<<<dim3((w + 255) / 256, h), 256, 0, st>>>((const int16_t *)ctx->lrd.p, d_disp, w, h);
+    r3d_prof_mark(ctx, ws, st, "median3");
+    k_median3<<<dim3((w + 255) / 256, h), 256, 0, st>>>((const int16_t *)ws.lrd.p, d_disp, w, h);
     R3D_HIP(ctx, hipGetLastError());
     if (p->speckleWindowSize > 0) {
-        r3d_prof_mark(ctx, "speckles");
-        if ((rc = r3d_speckle_run(ctx, d_disp, w, h, g.invalid, p->speckleWindowSize, 16 * p->speckleRange))) return rc;
+        r3d_prof_mark(ctx, ws, st, "speckles");
+        if ((rc = r3d_speckle_run(ctx, ws, st, d_disp, w, h, g.invalid, p->speckleWindowSize, 16 * p->speckleRange))) return rc;
     }
-    r3d_prof_end(ctx);
+    r3d_prof_end(ctx, ws, st);
     return R3D_OK;
 }

@@ -82,6 +82,36 @@ class StereoSGBM:
         self.context.call("r3d_sgbm_compute_dev", ctypes.byref(p), vp(d_left), vp(d_right), int(width), int(height),
                           int(stride), vp(d_disp))
 
+    def compute_batch_device(self, d_lefts, d_rights, width, height, stride, d_disps):
+        """Device-pointer batch (lists of ints): maps are pipelined over the library's internal lanes."""
+        n = len(d_lefts)
+        assert len(d_rights) == n and len(d_disps) == n
+        arr = ctypes.c_void_p * n
+        p = self.params_struct()
+        self.context.call("r3d_sgbm_compute_batch_dev", ctypes.byref(p), n, arr(*d_lefts), arr(*d_rights), int(width),
+                          int(height), int(stride), arr(*d_disps))
+
+    def compute_batch(self, lefts, rights):
+        """lefts / rights: sequences of uint8 [H,W] images of equal size -> list of int16 disparity maps."""
+        ctx = self.context
+        H, W = np.asarray(lefts[0]).shape
+        dl = [ctx.to_device(np.ascontiguousarray(a, dtype=np.uint8)) for a in lefts]
+        dr = [ctx.to_device(np.ascontiguousarray(a, dtype=np.uint8)) for a in rights]
+        dd = [ctx.alloc(W * H * 2) for _ in lefts]
+        try:
+            self.compute_batch_device(dl, dr, W, H, W, dd)
+            ctx.sync()
+            out = []
+            for d in dd:
+                a = np.empty((H, W), np.int16)
+                ctx.d2h(a, d)
+                out.append(a)
+        finally:
+            for q in dl + dr + dd:
+                ctx.free(q)
+        self._last_shape = (H, W)
+        return out
+
     def debug_fetch(self, want_cost=False, want_hsum=False, want_raw=True):
         """Stage outputs of the last compute (parity tests): dict of int16 arrays."""
         ctx = self.context

