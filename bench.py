@@ -81,7 +81,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gicp", action="store_true", help="skip the secondary metric (GICP iterations/s at 1M points)")
-    ap.add_argument("--lanes", type=int, default=3, help="maps in flight per GPU (1 = strictly one map after the other)")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="maps in flight per GPU. 1 (default): strictly one map after the other, so that the per-kernel HIP-event "
+                         "durations behind `roofline` are uncontended and agree with rocprofv3 --stats; 3: the K maps go through "
+                         "r3d_sgbm_compute_batch_dev and overlap on the library's internal lanes (+14 %% maps/s on C2)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,8 +113,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        m.compute_device(dL, dR, W, H, W, dD)
+    if lanes == 1:
+        for _ in range(args.warmup):
+            m.compute_device(dL, dR, W, H, W, dD)
+    else:                                        # warm every lane (workspace allocation happens at a lane's first use)
+        nw = max(args.warmup, lanes)
+        m.compute_batch_device([dL] * nw, [dR] * nw, W, H, W, [dDs[i % lanes] for i in range(nw)])
     ctx.set_profiling(True)
     ctx.sgbm_profile()                         # reset accumulators
     barrier()
