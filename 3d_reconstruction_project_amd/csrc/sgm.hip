@@ -412,12 +412,12 @@ constexpr int COST2_NWAVE = 8;
 // VCH (v3): the vertical path L_top is aggregated right here, on the freshly summed block cost that is still in
 // registers: one workgroup column-tile per STRIPE marches from the stripe's first warm-up row to its last row, and
 // writes C and L_top for the rows the stripe owns (the warm-up rows' special block costs never leave the chip).
-template <int LPC, int SH2, bool TRACK, bool VCH>
-__global__ void __launch_bounds__(COST2_NWAVE * 64) k_cost2(const uint2 *__restrict__ recL, const uint2 *__restrict__ recR, SgmGeom g,
+template <int LPC, int SH2, bool TRACK, bool VCH, int NWAVE>
+__global__ void __launch_bounds__(NWAVE * 64) k_cost2(const uint2 *__restrict__ recL, const uint2 *__restrict__ recR, SgmGeom g,
                                                             int *__restrict__ cvol, int *__restrict__ cspec, int BAND, int nMain,
                                                             int *__restrict__ maxc, int *__restrict__ ltvol) {
-    constexpr int NPL = 8, CW = 64 / LPC, TC = COST2_NWAVE * CW, TO = TC - 2 * SH2, DP = 16 * LPC, DPW = NPL * LPC;
-    constexpr int R = 2 * SH2 + 1, NRR = TC + DP, NT = COST2_NWAVE * 64;
+    constexpr int NPL = 8, CW = 64 / LPC, TC = NWAVE * CW, TO = TC - 2 * SH2, DP = 16 * LPC, DPW = NPL * LPC;
+    constexpr int R = 2 * SH2 + 1, NRR = TC + DP, NT = NWAVE * 64;
     // pair words: 6 dwords per right pixel, plus 8 dwords of padding after every 16 pixels: lanes of one column group
     // read records 16 apart (16*6 dwords = 32 mod 64 banks -> 4-way conflicts); with the pad the eight chunks land on
     // eight different multiples of 8 banks and the four column groups of a half-wave fill the gaps: conflict-free.
@@ -1112,14 +1112,13 @@ __global__ void __launch_bounds__(64) k_hscan3(const int *__restrict__ cvol, con
 // k_vscan2: vertical path + winner-take-all with 16 disparities per lane (NPL = 8): LPC = DP/16 lanes per column,
 // CPW = 64/LPC adjacent columns per wave, each column an independent chain inside its lane group.  Everything after
 // the path step -- argmin (32-bit keys cost<<16|d, v_min3 tree + group butterfly), uniqueness (packed compare against
-// the per-column threshold, counted), sub-pixel (the two neighbours of the winner are fetched through a per-wave LDS
-// image of S) -- is per-lane VALU work: no scalar unit traffic, no serialisation over columns.
+// the per-column threshold, counted), sub-pixel (the owner lane picks the winner's two neighbours out of its registers,
+// a 3-stage butterfly shares them) -- is per-lane VALU work: no scalar unit traffic, no LDS, no barrier.
 template <int LPC>
 __global__ void __launch_bounds__(64) k_vscan2(const int *__restrict__ cvol, const int *__restrict__ cspec,
                                                const int *__restrict__ hvol, SgmGeom g, float inv_a, int16_t *__restrict__ raw,
                                                int16_t *__restrict__ mins) {
     constexpr int NPL = 8, CPW = 64 / LPC, DPW = NPL * LPC;  // DPW words per column
-    __shared__ int sS[64 * NPL];
     const int lane = threadIdx.x, k = lane % LPC, grp = lane / LPC, n = blockIdx.y;
     const int xc = blockIdx.x * CPW + grp;
     const bool col_ok = xc < g.W1;
@@ -1164,15 +1163,19 @@ __global__ void __launch_bounds__(64) k_vscan2(const int *__restrict__ cvol, con
         if (!valid) key = 0x7fffffff;
         key = grp_allmin<LPC>(key);
         const int best = key & 0xffff, minS = key >> 16;
-        // per-wave LDS image of S: the winner's neighbours are read back with a per-lane (per-column) address
-        __syncthreads();
-        *(int4 *)&sS[lane * NPL] = make_int4(S[0], S[1], S[2], S[3]);
-        *(int4 *)&sS[lane * NPL + 4] = make_int4(S[4], S[5], S[6], S[7]);
-        __syncthreads();
-        const int gbase = (lane - k) * NPL;
+        // the winner's neighbours S[best-1], S[best+1]: the lane that owns the disparity picks it out of its registers
+        // with a select tree (the index is group-uniform, no LDS round trip, no barrier) and a 3-stage butterfly
+        // hands it to the whole group
+        auto fetch_s = [&](int d) -> int {
+            const int j = (d >> 1) & 7;
+            const int t0 = (j & 1) ? S[1] : S[0], t1 = (j & 1) ? S[3] : S[2], t2 = (j & 1) ? S[5] : S[4], t3 = (j & 1) ? S[7] : S[6];
+            const int u0 = (j & 2) ? t1 : t0, u1 = (j & 2) ? t3 : t2;
+            const int v = (j & 4) ? u1 : u0;
+            const int val = (d & 1) ? hi16(v) : lo16(v);
+            return grp_allmin<LPC>(((d >> 4) == k) ? val : 0x7fffffff);
+        };
         const int dm = max(best - 1, 0), dp = min(best + 1, g.D - 1);
-        const int wm = sS[gbase + (dm >> 1)], wp = sS[gbase + (dp >> 1)];
-        const int sm = (dm & 1) ? hi16(wm) : lo16(wm), sp = (dp & 1) ? hi16(wp) : lo16(wp);
+        const int sm = fetch_s(dm), sp = fetch_s(dp);
         bool bad = false;
         if (g.uniq > 0) {
             // S*a < minS*100  <=>  S < T ; count the disparities below T, subtract those inside [best-1, best+1]
@@ -1538,14 +1541,14 @@ int derive_geom(r3d_ctx *ctx, const r3d_sgbm_params *p, int w, int h, SgmGeom &g
     return R3D_OK;
 }
 
-template <int LPC, int SH2, bool TRACK, bool VCH>
-int launch_cost2_t(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st) {
-    constexpr int CW = 64 / LPC, TC = COST2_NWAVE * CW, TO = TC - 2 * SH2;
-    static_assert(TO > 0, "tile too small for this block size");
+template <int LPC, int SH2, bool TRACK, bool VCH, int NWAVE>
+int launch_cost2_n(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st) {
+    constexpr int CW = 64 / LPC, TC = NWAVE * CW, TO = TC - 2 * SH2;
+    if (TO <= 0) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "sgbm: tile too small for this block size");
     const int tiles = (g.W1 + TO - 1) / TO;
     // size the row bands so that one round of workgroups fills the chip (each band pays 2*SH2 extra rows of pixel cost)
     int per_cu = 1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_cost2<LPC, SH2, TRACK, VCH>, COST2_NWAVE * 64, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_cost2<LPC, SH2, TRACK, VCH, NWAVE>, NWAVE * 64, 0);
     if (per_cu < 1) per_cu = 1;
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
@@ -1558,7 +1561,7 @@ int launch_cost2_t(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t s
     const int nSpec = SH2 > 0 ? 3 : 0;
     int *maxc = (int *)ws.flags.p + 8;
     if (TRACK) R3D_HIP(ctx, hipMemsetAsync(maxc, 0, 4, st));
-    k_cost2<LPC, SH2, TRACK, VCH><<<dim3(tiles, VCH ? 4 : nMain + nSpec), COST2_NWAVE * 64, 0, st>>>(
+    k_cost2<LPC, SH2, TRACK, VCH, NWAVE><<<dim3(tiles, VCH ? 4 : nMain + nSpec), NWAVE * 64, 0, st>>>(
         (const uint2 *)ws.rec_l.p, (const uint2 *)ws.rec_r.p, g, (int *)ws.cost.p, (int *)ws.cspec.p, BAND, nMain, maxc, (int *)ws.ltop.p);
     R3D_HIP(ctx, hipGetLastError());
     if (TRACK) {
@@ -1570,6 +1573,15 @@ int launch_cost2_t(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t s
             return r3d_fail(ctx, R3D_E_UNSUPPORTED, "sgbm: block cost reaches %d > 16383 on this image pair; outside the exact int16 envelope", m);
     }
     return R3D_OK;
+}
+template <int LPC, int SH2, bool TRACK, bool VCH>
+int launch_cost2_t(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st) {
+    // 8 waves = 64-column tiles (2*SH2 halo columns); R3D_COST_NWAVE=4 selects 32-column tiles for A/B measurements
+    static const bool four = [] { const char *e = getenv("R3D_COST_NWAVE"); return e && !strcmp(e, "4"); }();
+    if constexpr (LPC == 8 && 4 * (64 / LPC) > 2 * SH2) {
+        if (four) return launch_cost2_n<LPC, SH2, TRACK, VCH, 4>(ctx, ws, g, st);
+    }
+    return launch_cost2_n<LPC, SH2, TRACK, VCH, 8>(ctx, ws, g, st);
 }
 template <int LPC, bool VCH>
 int launch_cost2_l(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st) {
