@@ -1114,11 +1114,12 @@ __global__ void __launch_bounds__(64) k_hscan3(const int *__restrict__ cvol, con
 // the path step -- argmin (32-bit keys cost<<16|d, v_min3 tree + group butterfly), uniqueness (packed compare against
 // the per-column threshold, counted), sub-pixel (the owner lane picks the winner's two neighbours out of its registers,
 // a 3-stage butterfly shares them) -- is per-lane VALU work: no scalar unit traffic, no LDS, no barrier.
-template <int LPC>
+template <int NPL, int LPC>
 __global__ void __launch_bounds__(64) k_vscan2(const int *__restrict__ cvol, const int *__restrict__ cspec,
                                                const int *__restrict__ hvol, SgmGeom g, float inv_a, int16_t *__restrict__ raw,
                                                int16_t *__restrict__ mins) {
-    constexpr int NPL = 8, CPW = 64 / LPC, DPW = NPL * LPC;  // DPW words per column
+    constexpr int CPW = 64 / LPC, DPW = NPL * LPC;  // columns per wave, words per column
+    static_assert(NPL == 4 || NPL == 8, "one or two 16-byte loads per lane");
     const int lane = threadIdx.x, k = lane % LPC, grp = lane / LPC, n = blockIdx.y;
     const int xc = blockIdx.x * CPW + grp;
     const bool col_ok = xc < g.W1;
@@ -1127,7 +1128,7 @@ __global__ void __launch_bounds__(64) k_vscan2(const int *__restrict__ cvol, con
     const int src_end = min((n + 1) * g.stripe_sz, g.H);
     const int out_start = min(n * g.stripe_sz, g.H);
     if (src_start >= src_end) return;
-    const bool valid = 16 * k < g.D, first = k == 0, last = k == LPC - 1;
+    const bool valid = 2 * NPL * k < g.D, first = k == 0, last = k == LPC - 1;
     const int P1pk = pk_dup(g.P1);
     const size_t off = (size_t)min(xc, g.W1 - 1) * DPW + k * NPL;
     const int a = 100 - g.uniq;
@@ -1139,12 +1140,14 @@ __global__ void __launch_bounds__(64) k_vscan2(const int *__restrict__ cvol, con
         const int yy = min(y, src_end - 1);
         const int *cr = ((n > 0 && yy < src_start + g.SH2) ? cspec + ((size_t)(n - 1) * g.SH2 + (yy - src_start)) * rowWords
                                                              : cvol + (size_t)yy * rowWords) + off;
-        const int4 c0 = *(const int4 *)cr, c1 = *(const int4 *)(cr + 4);
-        cb[0] = c0.x; cb[1] = c0.y; cb[2] = c0.z; cb[3] = c0.w; cb[4] = c1.x; cb[5] = c1.y; cb[6] = c1.z; cb[7] = c1.w;
+        const int4 c0 = *(const int4 *)cr;
+        cb[0] = c0.x; cb[1] = c0.y; cb[2] = c0.z; cb[3] = c0.w;
+        if constexpr (NPL == 8) { const int4 c1 = *(const int4 *)(cr + 4); cb[4] = c1.x; cb[5] = c1.y; cb[6] = c1.z; cb[7] = c1.w; }
         if (yy >= out_start) {
             const int *hr = hvol + (size_t)yy * rowWords + off;
-            const int4 h0 = *(const int4 *)hr, h1 = *(const int4 *)(hr + 4);
-            hb[0] = h0.x; hb[1] = h0.y; hb[2] = h0.z; hb[3] = h0.w; hb[4] = h1.x; hb[5] = h1.y; hb[6] = h1.z; hb[7] = h1.w;
+            const int4 h0 = *(const int4 *)hr;
+            hb[0] = h0.x; hb[1] = h0.y; hb[2] = h0.z; hb[3] = h0.w;
+            if constexpr (NPL == 8) { const int4 h1 = *(const int4 *)(hr + 4); hb[4] = h1.x; hb[5] = h1.y; hb[6] = h1.z; hb[7] = h1.w; }
         }
     };
     auto process = [&](int y, int (&cb)[NPL], int (&hb)[NPL]) {
@@ -1155,7 +1158,7 @@ __global__ void __launch_bounds__(64) k_vscan2(const int *__restrict__ cvol, con
 #pragma unroll
         for (int j = 0; j < NPL; j++) {
             S[j] = pk_add_sat(hb[j], P[j]);
-            const int d0 = 16 * k + 2 * j;
+            const int d0 = 2 * NPL * k + 2 * j;
             const int k0 = (int)((unsigned)S[j] << 16) | d0;              // (cost of d0) << 16 | d0, signed order
             const int k1 = (S[j] & (int)0xffff0000) | (d0 + 1);
             key = min(key, min(k0, k1));
@@ -1167,12 +1170,18 @@ __global__ void __launch_bounds__(64) k_vscan2(const int *__restrict__ cvol, con
         // with a select tree (the index is group-uniform, no LDS round trip, no barrier) and a 3-stage butterfly
         // hands it to the whole group
         auto fetch_s = [&](int d) -> int {
-            const int j = (d >> 1) & 7;
-            const int t0 = (j & 1) ? S[1] : S[0], t1 = (j & 1) ? S[3] : S[2], t2 = (j & 1) ? S[5] : S[4], t3 = (j & 1) ? S[7] : S[6];
-            const int u0 = (j & 2) ? t1 : t0, u1 = (j & 2) ? t3 : t2;
-            const int v = (j & 4) ? u1 : u0;
+            const int j = (d >> 1) % NPL;
+            int v;
+            if constexpr (NPL == 8) {
+                const int t0 = (j & 1) ? S[1] : S[0], t1 = (j & 1) ? S[3] : S[2], t2 = (j & 1) ? S[5] : S[4], t3 = (j & 1) ? S[7] : S[6];
+                const int u0 = (j & 2) ? t1 : t0, u1 = (j & 2) ? t3 : t2;
+                v = (j & 4) ? u1 : u0;
+            } else {
+                const int t0 = (j & 1) ? S[1] : S[0], t1 = (j & 1) ? S[3] : S[2];
+                v = (j & 2) ? t1 : t0;
+            }
             const int val = (d & 1) ? hi16(v) : lo16(v);
-            return grp_allmin<LPC>(((d >> 4) == k) ? val : 0x7fffffff);
+            return grp_allmin<LPC>(((d / (2 * NPL)) == k) ? val : 0x7fffffff);
         };
         const int dm = max(best - 1, 0), dp = min(best + 1, g.D - 1);
         const int sm = fetch_s(dm), sp = fetch_s(dp);
@@ -1181,7 +1190,7 @@ __global__ void __launch_bounds__(64) k_vscan2(const int *__restrict__ cvol, con
             // S*a < minS*100  <=>  S < T ; count the disparities below T, subtract those inside [best-1, best+1]
             const int T = ceil_div_small(minS * 100, a, inv_a);
             int cnt;
-            if (T > 32767) cnt = valid ? 16 : 0;
+            if (T > 32767) cnt = valid ? 2 * NPL : 0;
             else {
                 const int Tpk = pk_dup(max(T, -32768));
                 int acc = 0;
@@ -1770,8 +1779,13 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
         constexpr int CPW = 8;
         dim3 grid((g.W1 + CPW - 1) / CPW, 4);
         if (!use_v1) {
-            if (g.NP == 1) k_vscan2<8><<<dim3((g.W1 + 7) / 8, 4), 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, inv_a, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
-            else k_vscan2<16><<<dim3((g.W1 + 3) / 4, 4), 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, inv_a, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
+            // D <= 128: 8 registers x 8 lanes per column = 8 columns per wave (1568 waves).  R3D_VSCAN_COLS=4 selects
+            // 4 registers x 16 lanes (3136 finer-grained waves): measured 1.15 ms against 0.89 ms, the extra
+            // cross-lane stages cost more than the better SIMD balance returns.
+            static const bool cols4 = [] { const char *e = getenv("R3D_VSCAN_COLS"); return e && !strcmp(e, "4"); }();
+            if (g.NP == 1 && cols4) k_vscan2<4, 16><<<dim3((g.W1 + 3) / 4, 4), 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, inv_a, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
+            else if (g.NP == 1) k_vscan2<8, 8><<<dim3((g.W1 + 7) / 8, 4), 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, inv_a, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
+            else k_vscan2<8, 16><<<dim3((g.W1 + 3) / 4, 4), 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, inv_a, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
         } else if (g.NP == 1) k_vscan<1, CPW><<<grid, 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
         else k_vscan<2, CPW><<<grid, 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
         R3D_HIP(ctx, hipGetLastError());
