@@ -25,8 +25,8 @@ namespace {
 struct GridView {
     double ox, oy, oz, cell, inv_cell;
     int nx, ny, nz;
-    const int *cstart;     // [ncells] first sorted slot of the cell
-    const int *cend;       // [ncells] one past the last
+    const int *cstart;     // [ncells + 1] first sorted slot of every cell (exclusive scan of the cell populations);
+                           // x is the fastest key digit, so cells adjacent in x hold ONE contiguous run of points
     const double *pts;     // [n][3] points in cell-sorted order
     const int *idx;        // [n] sorted slot -> original index
 };
@@ -72,13 +72,20 @@ __global__ void __launch_bounds__(256) k_cell_keys(const double *__restrict__ p,
     vals[i] = (int)i;
 }
 
-__global__ void __launch_bounds__(256) k_cell_bounds(const unsigned long long *__restrict__ keys, int64_t n, int *__restrict__ cstart,
-                                                     int *__restrict__ cend) {
+// population of every cell: the last point of a run of equal (sorted) keys knows the run length
+__global__ void __launch_bounds__(256) k_cell_counts(const unsigned long long *__restrict__ keys, int64_t n, int *__restrict__ run_start,
+                                                     int *__restrict__ counts) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     unsigned long long k = keys[i];
-    if (i == 0 || keys[i - 1] != k) cstart[k] = (int)i;
-    if (i == n - 1 || keys[i + 1] != k) cend[k] = (int)i + 1;
+    if (i == 0 || keys[i - 1] != k) run_start[k] = (int)i;
+}
+__global__ void __launch_bounds__(256) k_cell_counts2(const unsigned long long *__restrict__ keys, int64_t n, const int *__restrict__ run_start,
+                                                      int *__restrict__ counts) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long k = keys[i];
+    if (i == n - 1 || keys[i + 1] != k) counts[k] = (int)i + 1 - run_start[k];
 }
 
 __global__ void __launch_bounds__(256) k_gather3(const double *__restrict__ src, const int *__restrict__ idx, int64_t n, double *__restrict__ dst) {
@@ -129,9 +136,27 @@ __device__ __forceinline__ void for_shell(const GridView &g, int cx, int cy, int
                 int x = cx + dx;
                 if (x < 0 || x >= g.nx) continue;
                 int64_t c = ((int64_t)z * g.ny + y) * g.nx + x;
-                int b = g.cstart[c], e = g.cend[c];
+                int b = g.cstart[c], e = g.cstart[c + 1];
                 if (e > b) f(b, e);
             }
+        }
+    }
+}
+
+// the 3x3x3 block around (cx,cy,cz) as NINE runs: the three cells of an x-row are contiguous in the sorted point array
+template <class F>
+__device__ __forceinline__ void for_block3(const GridView &g, int cx, int cy, int cz, F &&f) {
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+    if (x0 > x1) return;
+    for (int dz = -1; dz <= 1; dz++) {
+        const int z = cz + dz;
+        if (z < 0 || z >= g.nz) continue;
+        for (int dy = -1; dy <= 1; dy++) {
+            const int y = cy + dy;
+            if (y < 0 || y >= g.ny) continue;
+            const int64_t row = ((int64_t)z * g.ny + y) * g.nx;
+            const int b = g.cstart[row + x0], e = g.cstart[row + x1 + 1];
+            if (e > b) f(b, e);
         }
     }
 }
@@ -152,31 +177,33 @@ __device__ __forceinline__ int knn_query(const GridView &g, double qx, double qy
     int cnt = 0;
     const int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
     const int smax = max_shell(g, min(max(cx, 0), g.nx - 1), min(max(cy, 0), g.ny - 1), min(max(cz, 0), g.nz - 1)) + 1;
-    for (int s = 0; s <= smax; s++) {
-        for_shell(g, cx, cy, cz, s, [&](int b, int e) {
-            for (int i = b; i < e; i++) {
-                double dx = g.pts[(int64_t)i * 3] - qx, dy = g.pts[(int64_t)i * 3 + 1] - qy, dz = g.pts[(int64_t)i * 3 + 2] - qz;
-                double d2 = dx * dx + dy * dy + dz * dz;
-                if (!(d2 < r2)) continue;
-                // total order (d2, original index): exact-distance ties are common on voxelised / fp32-rounded clouds,
-                // and the oracle breaks them the same way
-                if (cnt == k) {
-                    const double worst = sd[(k - 1) * KNN_BLOCK + t];
-                    if (d2 > worst || (d2 == worst && g.idx[i] > g.idx[si[(k - 1) * KNN_BLOCK + t]])) continue;
-                }
-                int pos = cnt < k ? cnt : k - 1;
-                while (pos > 0) {
-                    const double pd = sd[(pos - 1) * KNN_BLOCK + t];
-                    if (!(pd > d2 || (pd == d2 && g.idx[si[(pos - 1) * KNN_BLOCK + t]] > g.idx[i]))) break;
-                    sd[pos * KNN_BLOCK + t] = pd;
-                    si[pos * KNN_BLOCK + t] = si[(pos - 1) * KNN_BLOCK + t];
-                    pos--;
-                }
-                sd[pos * KNN_BLOCK + t] = d2;
-                si[pos * KNN_BLOCK + t] = i;
-                if (cnt < k) cnt++;
+    auto visit = [&](int b, int e) {
+        for (int i = b; i < e; i++) {
+            double dx = g.pts[(int64_t)i * 3] - qx, dy = g.pts[(int64_t)i * 3 + 1] - qy, dz = g.pts[(int64_t)i * 3 + 2] - qz;
+            double d2 = dx * dx + dy * dy + dz * dz;
+            if (!(d2 < r2)) continue;
+            // total order (d2, original index): exact-distance ties are common on voxelised / fp32-rounded clouds,
+            // and the oracle breaks them the same way
+            if (cnt == k) {
+                const double worst = sd[(k - 1) * KNN_BLOCK + t];
+                if (d2 > worst || (d2 == worst && g.idx[i] > g.idx[si[(k - 1) * KNN_BLOCK + t]])) continue;
             }
-        });
+            int pos = cnt < k ? cnt : k - 1;
+            while (pos > 0) {
+                const double pd = sd[(pos - 1) * KNN_BLOCK + t];
+                if (!(pd > d2 || (pd == d2 && g.idx[si[(pos - 1) * KNN_BLOCK + t]] > g.idx[i]))) break;
+                sd[pos * KNN_BLOCK + t] = pd;
+                si[pos * KNN_BLOCK + t] = si[(pos - 1) * KNN_BLOCK + t];
+                pos--;
+            }
+            sd[pos * KNN_BLOCK + t] = d2;
+            si[pos * KNN_BLOCK + t] = i;
+            if (cnt < k) cnt++;
+        }
+    };
+    for (int s = 1; s <= smax; s++) {
+        if (s == 1) for_block3(g, cx, cy, cz, visit);      // shells 0 and 1 as nine contiguous runs
+        else for_shell(g, cx, cy, cz, s, visit);
         // everything not visited yet is at least s*cell away
         const double reach = s * g.cell;
         if (radius > 0 && reach >= radius) break;
@@ -284,13 +311,14 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_knn_score(GridView g, int64_t n, 
         const int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
         int c = 0;
         const int smax = (int)ceil(count_radius * g.inv_cell);
-        for (int s = 0; s <= smax; s++)
-            for_shell(g, cx, cy, cz, s, [&](int b, int e) {
-                for (int j = b; j < e; j++) {
-                    double dx = g.pts[(int64_t)j * 3] - qx, dy = g.pts[(int64_t)j * 3 + 1] - qy, dz = g.pts[(int64_t)j * 3 + 2] - qz;
-                    if (dx * dx + dy * dy + dz * dz <= r2) c++;
-                }
-            });
+        auto count = [&](int b, int e) {
+            for (int j = b; j < e; j++) {
+                double dx = g.pts[(int64_t)j * 3] - qx, dy = g.pts[(int64_t)j * 3 + 1] - qy, dz = g.pts[(int64_t)j * 3 + 2] - qz;
+                if (dx * dx + dy * dy + dz * dz <= r2) c++;
+            }
+        };
+        for_block3(g, cx, cy, cz, count);
+        for (int s = 2; s <= smax; s++) for_shell(g, cx, cy, cz, s, count);
         score[g.idx[i]] = (double)c;
         return;
     }
@@ -366,16 +394,18 @@ __global__ void __launch_bounds__(ICP_BLOCK) k_icp_eval(GridView g, const double
         double best = r2;
         int bi = -1;
         const int smax = (int)ceil(max_dist * g.inv_cell);
-        for (int s = 0; s <= smax; s++) {
-            for_shell(g, cx, cy, cz, s, [&](int b, int e) {
-                for (int j = b; j < e; j++) {
-                    double dx = g.pts[(int64_t)j * 3] - px, dy = g.pts[(int64_t)j * 3 + 1] - py, dz = g.pts[(int64_t)j * 3 + 2] - pz;
-                    double d2 = dx * dx + dy * dy + dz * dz;
-                    if (d2 <= best) {   // ties are rare: the index loads of the total order (d2, index) stay off the hot path
-                        if (d2 < best || (bi >= 0 && g.idx[j] < g.idx[bi])) { best = d2; bi = j; }
-                    }
+        auto visit = [&](int b, int e) {
+            for (int j = b; j < e; j++) {
+                double dx = g.pts[(int64_t)j * 3] - px, dy = g.pts[(int64_t)j * 3 + 1] - py, dz = g.pts[(int64_t)j * 3 + 2] - pz;
+                double d2 = dx * dx + dy * dy + dz * dz;
+                if (d2 <= best) {   // ties are rare: the index loads of the total order (d2, index) stay off the hot path
+                    if (d2 < best || (bi >= 0 && g.idx[j] < g.idx[bi])) { best = d2; bi = j; }
                 }
-            });
+            }
+        };
+        for (int s = 1; s <= max(smax, 1); s++) {
+            if (s == 1) for_block3(g, cx, cy, cz, visit);      // shells 0 and 1 as nine contiguous runs
+            else for_shell(g, cx, cy, cz, s, visit);
             const double reach = s * g.cell;
             if (bi >= 0 && best <= reach * reach) break;
         }
@@ -597,16 +627,24 @@ int grid_build(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, doubl
     int *idx;
     rc = sort_by_cell(ctx, ar, d_pts, n, G.mn, cell, dims, 0, &G.keys, &idx);
     if (rc) return rc;
-    int *cs = (int *)ar.get((size_t)G.ncells * 4), *ce = (int *)ar.get((size_t)G.ncells * 4);
+    int *cnt = (int *)ar.get((size_t)(G.ncells + 1) * 4), *rs = (int *)ar.get((size_t)(G.ncells + 1) * 4);
+    int *cs = (int *)ar.get((size_t)(G.ncells + 1) * 4);
     double *sorted = (double *)ar.get((size_t)n * 24);
     if (ar.rc) return ar.rc;
-    R3D_HIP(ctx, hipMemsetAsync(cs, 0, (size_t)G.ncells * 4, ctx->stream));
-    R3D_HIP(ctx, hipMemsetAsync(ce, 0, (size_t)G.ncells * 4, ctx->stream));
+    R3D_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)(G.ncells + 1) * 4, ctx->stream));
     const int nb = (int)((n + 255) / 256);
-    k_cell_bounds<<<nb, 256, 0, ctx->stream>>>(G.keys, n, cs, ce);
+    k_cell_counts<<<nb, 256, 0, ctx->stream>>>(G.keys, n, rs, cnt);
+    k_cell_counts2<<<nb, 256, 0, ctx->stream>>>(G.keys, n, rs, cnt);
+    {
+        size_t tb = 0;
+        R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, cs, (int)(G.ncells + 1), ctx->stream));
+        void *tmp = ar.get(tb);
+        if (ar.rc) return ar.rc;
+        R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, cs, (int)(G.ncells + 1), ctx->stream));
+    }
     k_gather3<<<nb, 256, 0, ctx->stream>>>(d_pts, idx, n, sorted);
     R3D_HIP(ctx, hipGetLastError());
-    G.v = GridView{G.mn[0], G.mn[1], G.mn[2], cell, 1.0 / cell, dims[0], dims[1], dims[2], cs, ce, sorted, idx};
+    G.v = GridView{G.mn[0], G.mn[1], G.mn[2], cell, 1.0 / cell, dims[0], dims[1], dims[2], cs, sorted, idx};
     return R3D_OK;
 }
 
