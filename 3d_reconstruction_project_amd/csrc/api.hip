@@ -104,6 +104,10 @@ void r3d_destroy(r3d_ctx *ctx) {
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     for (r3d_buf &b : ctx->cloud_bufs)
         if (b.p) (void)hipFree(b.p);
+    for (r3d_buf &b : ctx->pp_bufs)
+        if (b.p) (void)hipFree(b.p);
+    if (ctx->pp_minmax.p) (void)hipFree(ctx->pp_minmax.p);
+    if (ctx->pp_lut.p) (void)hipFree(ctx->pp_lut.p);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -6,5 +6,5 @@ out="$here/../lib"
 mkdir -p "$out"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "$HIPCC" --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -fPIC -shared -Wall -Wno-unused-function \
-    "$@" "$here"/api.hip "$here"/sgm.hip $(ls "$here"/cloud.hip 2>/dev/null || true) -o "$out/libr3d_hip.so"
+    "$@" "$here"/api.hip "$here"/sgm.hip "$here"/cloud.hip "$here"/prepost.hip -o "$out/libr3d_hip.so"
 echo "built $out/libr3d_hip.so"

@@ -56,6 +56,11 @@ struct r3d_ctx {
     int n_acc = 0;
     // cloud workspace (cloud.hip)
     std::vector<r3d_buf> cloud_bufs;
+    // pre/post-processing workspace (prepost.hip)
+    std::vector<r3d_buf> pp_bufs;
+    r3d_buf pp_minmax, pp_lut;
+    double pp_lut_sigma = -1.0;
+    int pp_lut_n = 0;
 };
 
 int r3d_fail(r3d_ctx *ctx, int code, const char *fmt, ...);

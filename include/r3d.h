@@ -174,6 +174,60 @@ typedef struct {
 int r3d_icp(r3d_ctx *ctx, const r3d_icp_params *p, const double *src, int64_t ns, const double *src_normals, const double *tgt,
             int64_t nt, const double *tgt_normals, const double *init4x4, double *T4x4, r3d_icp_stats *stats);
 
+/* ---- per-frame stages either side of the matcher in Calib_depth/depth*.py --------------
+ * OpenCV is a dependency of the reference that is absent here, and the reference records no output of these calls:
+ * parity of this group is UNPINNED (restated from OpenCV 4.x's published algorithms; see oracle/prepost_oracle.py). */
+
+/* replaces: cv2.initUndistortRectifyMap(mtx, dist, R, P, image_size, cv2.CV_16SC2)   depth2.py:125-128 (depth1.py:208-211)
+ * camera3x3 row-major; dist: n_dist in {0,4,5,8,12,14} coefficients k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4 tx ty (tilt must be
+ * 0); R3x3 may be NULL (identity); new_camera: 3 x new_camera_cols (3 or 4) row-major, the projection matrix P1/P2 as
+ * stored in the calibration file.  Host outputs: map1 int16 [h][w][2] (integer source x, y), map2 uint16 [h][w]
+ * (5+5 fraction bits, INTER_TAB_SIZE = 32).  fp64, running sums along each row like the original's scalar loop. */
+int r3d_init_undistort_rectify_map(r3d_ctx *ctx, const double *camera3x3, const double *dist, int32_t n_dist, const double *R3x3,
+                                   const double *new_camera, int32_t new_camera_cols, int32_t w, int32_t h, int16_t *map1,
+                                   uint16_t *map2);
+
+/* replaces: cv2.remap(frame, map_x, map_y, cv2.INTER_LINEAR)   depth2.py:243-244
+ * uint8 source with cn = 1, 3 or 4 interleaved channels, fixed-point maps as above, BORDER_CONSTANT(border_value):
+ * dst = (sum of 4 taps x 15-bit table weights + 2^14) >> 15.  gray (may be NULL, needs cn >= 3): the BGR2GRAY image of the
+ * remapped frame written by the same kernel (depth2.py:247-248 converts the rectified frame right away). */
+int r3d_remap_u8(r3d_ctx *ctx, const uint8_t *src, int32_t sw, int32_t sh, int32_t sstride, int32_t cn, const int16_t *map1,
+                 const uint16_t *map2, int32_t dw, int32_t dh, int32_t border_value, uint8_t *dst, uint8_t *gray);
+int r3d_remap_u8_dev(r3d_ctx *ctx, const uint8_t *d_src, int32_t sw, int32_t sh, int32_t sstride, int32_t cn,
+                     const int16_t *d_map1, const uint16_t *d_map2, int32_t dw, int32_t dh, int32_t border_value, uint8_t *d_dst,
+                     uint8_t *d_gray);
+
+/* replaces: cv2.cvtColor(img, cv2.COLOR_BGR2GRAY)   depth2.py:247-248:  (B*1868 + G*9617 + R*4899 + 2^13) >> 14 */
+int r3d_bgr2gray(r3d_ctx *ctx, const uint8_t *bgr, int32_t w, int32_t h, int32_t stride, int32_t cn, uint8_t *gray);
+int r3d_bgr2gray_dev(r3d_ctx *ctx, const uint8_t *d_bgr, int32_t w, int32_t h, int32_t stride, int32_t cn, uint8_t *d_gray);
+
+/* replaces: wls_filter = cv2.ximgproc.createDisparityWLSFilter(matcher_left=stereo_matcher); setLambda(8000);
+ * setSigmaColor(1.5)   depth2.py:164-166;   wls_filter.filter(disparity_left, gray_left, None, disparity_right)   :255 */
+typedef struct r3d_wls_params {
+    double lambda;                 /* setLambda */
+    double sigma_color;            /* setSigmaColor */
+    double lambda_attenuation;     /* 0.25 */
+    double discontinuity_roll_off; /* 0.001 */
+    int32_t min_disparity;         /* of the LEFT matcher: ROI = columns [max(0,minD+D), w - max(0,-minD)) */
+    int32_t num_disparities;
+    int32_t discontinuity_radius;  /* ceil(0.5*blockSize) for an SGBM matcher */
+    int32_t lrc_thresh;            /* 24 (1.5 px in x16 units) */
+    int32_t num_iter;              /* 3 */
+    int32_t reserved;
+} r3d_wls_params;
+/* disp_left / disp_right: int16 x16 maps of the left and the right matcher (the right one holds negative values);
+ * guide: uint8 left view with guide_cn = 1 or 3 channels.  out: int16 x16, 16*(minD-1) outside the ROI.
+ * confidence (may be NULL): float [h][w] map in [0,255] (getConfidenceMap()). */
+int r3d_wls_filter(r3d_ctx *ctx, const r3d_wls_params *p, const int16_t *disp_left, const int16_t *disp_right, const uint8_t *guide,
+                   int32_t guide_cn, int32_t guide_stride, int32_t w, int32_t h, int16_t *out, float *confidence);
+int r3d_wls_filter_dev(r3d_ctx *ctx, const r3d_wls_params *p, const int16_t *d_disp_left, const int16_t *d_disp_right,
+                       const uint8_t *d_guide, int32_t guide_cn, int32_t guide_stride, int32_t w, int32_t h, int16_t *d_out,
+                       float *d_confidence);
+
+/* replaces: cv2.normalize(filtered_disparity, None, 0, 255, cv2.NORM_MINMAX)   depth2.py:256 (int16 in, int16 out) */
+int r3d_normalize_minmax_s16(r3d_ctx *ctx, const int16_t *src, int64_t n, double alpha, double beta, int16_t *dst);
+int r3d_normalize_minmax_s16_dev(r3d_ctx *ctx, const int16_t *d_src, int64_t n, double alpha, double beta, int16_t *d_dst);
+
 #ifdef __cplusplus
 }
 #endif
