@@ -395,6 +395,220 @@ __global__ __launch_bounds__(64) void k_fgs_v(const float *__restrict__ C, float
     }
 }
 
+// ---- partitioned solver (default): the same tridiagonal systems, solved block-parallel -----------------------
+// Every 32nd unknown of a line (row for the horizontal pass, column for the vertical one) is a separator; the 31
+// unknowns between two separators form a block.  Given the separator values the blocks decouple, and the separators
+// satisfy a tridiagonal Schur-complement system of their own:
+//   A: per block, local Thomas solves of  T y = f (both signals),  T v = a_first e_first,  T w = c_last e_last;
+//      only the end values go to memory (record of 12 floats per line and block)
+//   R: per line, the reduced tridiagonal system over the separators (<= N/32 unknowns), both signals
+//   B: per block, f_first -= a_first*S_left, f_last -= c_last*S_right, local Thomas solve, result written in place
+// Exact in exact arithmetic; in float32 it differs from the sequential order by rounding only (tests state the bound).
+// A and B work on 64-line x 32-unknown tiles in LDS: 4 000 waves at 8 MP instead of 39, global traffic 8 floats/pixel.
+#define PT 32
+#define PREC 12  // record fields: yF1 yL1 yF2 yL2 vF vL wF wL a_s c_s fs1 fs2
+#define TILE_F (64 * 33)
+
+template <bool VERT>
+__device__ __forceinline__ int lidx(int lane, int j) { return VERT ? j * 64 + lane : lane * 33 + j; }
+
+// tile of 64 lines x 32 unknowns starting at unknown p of lines line0..: global (pitch W, H rows) -> LDS
+template <bool VERT>
+__device__ __forceinline__ void tile_load(const float *__restrict__ g, float *t, int W, int H, int line0, int p, int lane) {
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        int row, col, o;
+        if (VERT) { row = p + i; col = line0 + lane; o = i * 64 + lane; }
+        else { row = line0 + 2 * i + (lane >> 5); col = p + (lane & 31); o = (2 * i + (lane >> 5)) * 33 + (lane & 31); }
+        t[o] = (row < H && col < W) ? g[(size_t)row * W + col] : 0.f;
+    }
+}
+template <bool VERT>
+__device__ __forceinline__ void tile_store(float *__restrict__ g, const float *t, int W, int H, int line0, int p, int lane) {
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        int row, col, o;
+        if (VERT) { row = p + i; col = line0 + lane; o = i * 64 + lane; }
+        else { row = line0 + 2 * i + (lane >> 5); col = p + (lane & 31); o = (2 * i + (lane >> 5)) * 33 + (lane & 31); }
+        if (row < H && col < W) g[(size_t)row * W + col] = t[o];
+    }
+}
+
+template <bool VERT>
+__global__ __launch_bounds__(64) void k_fgs_pA(const float *__restrict__ C, const float *__restrict__ s0,
+                                               const float *__restrict__ s1, float *__restrict__ rec, int W, int H, float lam) {
+    __shared__ float tC[TILE_F], t0[TILE_F], t1[TILE_F], tv[TILE_F];
+    const int lane = threadIdx.x, k = blockIdx.x, line0 = blockIdx.y * 64;
+    const int N = VERT ? H : W, NL = VERT ? W : H;
+    const int p = k * PT, q = min(p + PT - 1, N), n = q - p;
+    tile_load<VERT>(C, tC, W, H, line0, p, lane);
+    tile_load<VERT>(s0, t0, W, H, line0, p, lane);
+    tile_load<VERT>(s1, t1, W, H, line0, p, lane);
+    __syncthreads();
+    const int line = line0 + lane;
+    if (line >= NL) return;
+    const float cl = p > 0 ? (VERT ? C[(size_t)(p - 1) * W + line] : C[(size_t)line * W + p - 1]) : 0.f;
+    const float a0 = lam * cl;
+    float cprev = cl, ccprev = 0.f, y1p = 0.f, y2p = 0.f, vp = 0.f, denom = 1.f;
+    for (int j = 0; j < n; j++) {
+        const int i = lidx<VERT>(lane, j);
+        const float craw = tC[i], a = lam * cprev, c = lam * craw;
+        const float diag = (1.0f - a) - c;
+        float y1 = t0[i], y2 = t1[i], v;
+        if (j > 0) {
+            denom = diag - a * ccprev;
+            y1 = (y1 - a * y1p) / denom;
+            y2 = (y2 - a * y2p) / denom;
+            v = (0.f - a * vp) / denom;
+        } else {
+            denom = diag;
+            y1 = y1 / denom;
+            y2 = y2 / denom;
+            v = a0 / denom;
+        }
+        const float cc = j < n - 1 ? c / denom : 0.f;
+        tC[i] = cc;
+        t0[i] = y1;
+        t1[i] = y2;
+        tv[i] = v;
+        cprev = craw; ccprev = cc; y1p = y1; y2p = y2; vp = v;
+    }
+    const float c_last = lam * cprev;  // coupling of the block's last unknown to its separator (0 when there is none)
+    float y1n = y1p, y2n = y2p, vn = vp, wn = c_last / denom;
+    const float yL1 = y1n, yL2 = y2n, vL = vn, wL = wn;
+    for (int j = n - 2; j >= 0; j--) {
+        const int i = lidx<VERT>(lane, j);
+        const float cc = tC[i];
+        y1n = t0[i] - cc * y1n;
+        y2n = t1[i] - cc * y2n;
+        vn = tv[i] - cc * vn;
+        wn = 0.f - cc * wn;
+    }
+    float a_s = 0.f, c_s = 0.f, fs1 = 0.f, fs2 = 0.f;
+    if (q < N) {  // this block is followed by a separator: unknown q = tile position 31 (untouched above since n = 31)
+        const int i = lidx<VERT>(lane, PT - 1);
+        a_s = c_last;
+        c_s = lam * tC[i];
+        fs1 = t0[i];
+        fs2 = t1[i];
+    }
+    float *r = rec + ((size_t)k * PREC) * NL + line;
+    r[0 * (size_t)NL] = y1n; r[1 * (size_t)NL] = yL1; r[2 * (size_t)NL] = y2n; r[3 * (size_t)NL] = yL2;
+    r[4 * (size_t)NL] = vn;  r[5 * (size_t)NL] = vL;  r[6 * (size_t)NL] = wn;  r[7 * (size_t)NL] = wL;
+    r[8 * (size_t)NL] = a_s; r[9 * (size_t)NL] = c_s; r[10 * (size_t)NL] = fs1; r[11 * (size_t)NL] = fs2;
+}
+
+// reduced system over the separators of each line; sol[(k*3 + {0: cc, 1: S of signal 0, 2: S of signal 1}) * NL + line]
+__global__ __launch_bounds__(64) void k_fgs_pR(const float *__restrict__ rec, float *__restrict__ sol, int N, int NL) {
+    const int line = blockIdx.x * 64 + threadIdx.x;
+    if (line >= NL) return;
+    const int P = N / PT, nb = (N + PT - 1) / PT;
+    float ccprev = 0.f, s1p = 0.f, s2p = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < P; k++) {
+        const float *r = rec + ((size_t)k * PREC) * NL + line;
+        const float yL1 = r[1 * (size_t)NL], yL2 = r[3 * (size_t)NL], vL = r[5 * (size_t)NL], wL = r[7 * (size_t)NL];
+        const float a_s = r[8 * (size_t)NL], c_s = r[9 * (size_t)NL];
+        float r1 = r[10 * (size_t)NL] - a_s * yL1, r2 = r[11 * (size_t)NL] - a_s * yL2;
+        const float ra = 0.f - a_s * vL;
+        float rb = ((1.0f - a_s) - c_s) - a_s * wL, rc = 0.f;
+        if (k + 1 < nb) {
+            const float *rn = r + (size_t)PREC * NL;
+            rb = rb - c_s * rn[4 * (size_t)NL];
+            rc = 0.f - c_s * rn[6 * (size_t)NL];
+            r1 = r1 - c_s * rn[0 * (size_t)NL];
+            r2 = r2 - c_s * rn[2 * (size_t)NL];
+        }
+        const float denom = rb - ra * ccprev;
+        ccprev = rc / denom;
+        s1p = (r1 - ra * s1p) / denom;
+        s2p = (r2 - ra * s2p) / denom;
+        float *o = sol + ((size_t)k * 3) * NL + line;
+        o[0] = ccprev;
+        o[(size_t)NL] = s1p;
+        o[2 * (size_t)NL] = s2p;
+    }
+#pragma unroll 4
+    for (int k = P - 2; k >= 0; k--) {
+        float *o = sol + ((size_t)k * 3) * NL + line;
+        const float cc = o[0];
+        s1p = o[(size_t)NL] - cc * s1p;
+        s2p = o[2 * (size_t)NL] - cc * s2p;
+        o[(size_t)NL] = s1p;
+        o[2 * (size_t)NL] = s2p;
+    }
+}
+
+template <bool VERT>
+__global__ __launch_bounds__(64) void k_fgs_pB(const float *__restrict__ C, float *__restrict__ s0, float *__restrict__ s1,
+                                               const float *__restrict__ sol, int W, int H, float lam) {
+    __shared__ float tC[TILE_F], t0[TILE_F], t1[TILE_F];
+    const int lane = threadIdx.x, k = blockIdx.x, line0 = blockIdx.y * 64;
+    const int N = VERT ? H : W, NL = VERT ? W : H;
+    const int p = k * PT, q = min(p + PT - 1, N), n = q - p;
+    tile_load<VERT>(C, tC, W, H, line0, p, lane);
+    tile_load<VERT>(s0, t0, W, H, line0, p, lane);
+    tile_load<VERT>(s1, t1, W, H, line0, p, lane);
+    __syncthreads();
+    const int line = line0 + lane;
+    if (line < NL) {
+        const float cl = p > 0 ? (VERT ? C[(size_t)(p - 1) * W + line] : C[(size_t)line * W + p - 1]) : 0.f;
+        float sl1 = 0.f, sl2 = 0.f, sr1 = 0.f, sr2 = 0.f;
+        if (k > 0) {
+            const float *o = sol + ((size_t)(k - 1) * 3) * NL + line;
+            sl1 = o[(size_t)NL];
+            sl2 = o[2 * (size_t)NL];
+        }
+        if (q < N) {
+            const float *o = sol + ((size_t)k * 3) * NL + line;
+            sr1 = o[(size_t)NL];
+            sr2 = o[2 * (size_t)NL];
+        }
+        const float a0 = lam * cl;
+        float cprev = cl, ccprev = 0.f, y1p = 0.f, y2p = 0.f;
+        for (int j = 0; j < n; j++) {
+            const int i = lidx<VERT>(lane, j);
+            const float craw = tC[i], a = lam * cprev, c = lam * craw;
+            const float diag = (1.0f - a) - c;
+            float y1 = t0[i], y2 = t1[i], denom;
+            if (j == n - 1) {  // coupling to the right separator moves to the right-hand side
+                y1 = y1 - c * sr1;
+                y2 = y2 - c * sr2;
+            }
+            if (j > 0) {
+                denom = diag - a * ccprev;
+                y1 = (y1 - a * y1p) / denom;
+                y2 = (y2 - a * y2p) / denom;
+            } else {
+                denom = diag;
+                y1 = (y1 - a0 * sl1) / denom;
+                y2 = (y2 - a0 * sl2) / denom;
+            }
+            const float cc = j < n - 1 ? c / denom : 0.f;
+            tC[i] = cc;
+            t0[i] = y1;
+            t1[i] = y2;
+            cprev = craw; ccprev = cc; y1p = y1; y2p = y2;
+        }
+        for (int j = n - 2; j >= 0; j--) {
+            const int i = lidx<VERT>(lane, j);
+            const float cc = tC[i];
+            y1p = t0[i] - cc * y1p;
+            y2p = t1[i] - cc * y2p;
+            t0[i] = y1p;
+            t1[i] = y2p;
+        }
+        if (q < N) {
+            const int i = lidx<VERT>(lane, PT - 1);
+            t0[i] = sr1;
+            t1[i] = sr2;
+        }
+    }
+    __syncthreads();
+    tile_store<VERT>(s0, t0, W, H, line0, p, lane);
+    tile_store<VERT>(s1, t1, W, H, line0, p, lane);
+}
+
 // out = short(round_half_even(sig0 * (1 / (sig1 + 1e-5)))) inside the ROI, 16*(minD-1) elsewhere
 __global__ void k_wls_finish(const float *__restrict__ sig0, const float *__restrict__ sig1, int W, int H, int lx, int lw,
                              int fill, int16_t *__restrict__ out) {
@@ -606,10 +820,27 @@ static int wls_run(r3d_ctx *ctx, PPArena &ar, const r3d_wls_params *p, const int
     if (gcn == 1) k_fgs_weights<1><<<groi, blk, 0, st>>>(d_guide, gstride, lx, lw, h, lut, ch, cv);
     else k_fgs_weights<3><<<groi, blk, 0, st>>>(d_guide, gstride, lx, lw, h, lut, ch, cv);
     float lam = (float)p->lambda;
-    for (int it = 0; it < p->num_iter; it++) {
-        k_fgs_h<<<(h + 63) / 64, 64, 0, st>>>(ch, cc, s0, s1, lw, h, lam);
-        k_fgs_v<<<(lw + 63) / 64, 64, 0, st>>>(cv, cc, s0, s1, lw, h, lam);
-        lam = lam * (float)p->lambda_attenuation;
+    if (p->solver == R3D_WLS_SOLVER_SEQUENTIAL) {
+        for (int it = 0; it < p->num_iter; it++) {
+            k_fgs_h<<<(h + 63) / 64, 64, 0, st>>>(ch, cc, s0, s1, lw, h, lam);
+            k_fgs_v<<<(lw + 63) / 64, 64, 0, st>>>(cv, cc, s0, s1, lw, h, lam);
+            lam = lam * (float)p->lambda_attenuation;
+        }
+    } else {
+        // records and separator solutions of the partitioned solver: 12 + 3 floats per line and block, either direction
+        const int nbh = (lw + PT - 1) / PT, nbv = (h + PT - 1) / PT;
+        const size_t nrec = std::max((size_t)nbh * h, (size_t)nbv * lw);
+        float *rec = (float *)ar.get(nrec * PREC * 4), *sol = (float *)ar.get(nrec * 3 * 4);
+        if (ar.rc) return ar.rc;
+        for (int it = 0; it < p->num_iter; it++) {
+            k_fgs_pA<false><<<dim3(nbh, (h + 63) / 64), 64, 0, st>>>(ch, s0, s1, rec, lw, h, lam);
+            k_fgs_pR<<<(h + 63) / 64, 64, 0, st>>>(rec, sol, lw, h);
+            k_fgs_pB<false><<<dim3(nbh, (h + 63) / 64), 64, 0, st>>>(ch, s0, s1, sol, lw, h, lam);
+            k_fgs_pA<true><<<dim3(nbv, (lw + 63) / 64), 64, 0, st>>>(cv, s0, s1, rec, lw, h, lam);
+            k_fgs_pR<<<(lw + 63) / 64, 64, 0, st>>>(rec, sol, h, lw);
+            k_fgs_pB<true><<<dim3(nbv, (lw + 63) / 64), 64, 0, st>>>(cv, s0, s1, sol, lw, h, lam);
+            lam = lam * (float)p->lambda_attenuation;
+        }
     }
     k_wls_finish<<<dim3((w + 255) / 256, h), blk, 0, st>>>(s0, s1, w, h, lx, lw, fill, d_out);
     R3D_HIP(ctx, hipGetLastError());
@@ -620,7 +851,7 @@ static int wls_check(r3d_ctx *ctx, const r3d_wls_params *p, int gcn, int w, int 
     if (!p || w <= 0 || h <= 0) return r3d_fail(ctx, R3D_E_BADARG, "wls_filter: bad argument");
     if (gcn != 1 && gcn != 3) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "wls_filter: guide with %d channels (1 or 3)", gcn);
     if (!(p->lambda >= 0) || !(p->sigma_color > 0) || p->num_iter < 1 || p->num_iter > 16 || p->discontinuity_radius < 0 ||
-        p->discontinuity_radius > 32 || p->num_disparities < 0)
+        p->discontinuity_radius > 32 || p->num_disparities < 0 || (p->solver != R3D_WLS_SOLVER_PARTITIONED && p->solver != R3D_WLS_SOLVER_SEQUENTIAL))
         return r3d_fail(ctx, R3D_E_BADARG, "wls_filter: bad parameter");
     if (h > 65535) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "wls_filter: more than 65535 rows");
     return R3D_OK;

@@ -26,12 +26,13 @@ INTER_LINEAR = 1         # cv2.INTER_LINEAR
 COLOR_BGR2GRAY = 6       # cv2.COLOR_BGR2GRAY
 NORM_MINMAX = 32         # cv2.NORM_MINMAX
 BORDER_CONSTANT = 0
+SOLVER_PARTITIONED, SOLVER_SEQUENTIAL = 0, 1     # r3d_wls_params.solver
 
 
 class WlsParams(ctypes.Structure):
     _fields_ = [("lambda_", ctypes.c_double), ("sigma_color", ctypes.c_double), ("lambda_attenuation", ctypes.c_double),
                 ("discontinuity_roll_off", ctypes.c_double), ("min_disparity", _i32), ("num_disparities", _i32),
-                ("discontinuity_radius", _i32), ("lrc_thresh", _i32), ("num_iter", _i32), ("reserved", _i32)]
+                ("discontinuity_radius", _i32), ("lrc_thresh", _i32), ("num_iter", _i32), ("solver", _i32)]
 
 
 _lib.register({
@@ -136,6 +137,7 @@ class DisparityWLSFilter:
         self._radius = int(math.ceil(0.5 * block_size))
         self._roll_off = 0.001
         self._device = device
+        self.solver = SOLVER_PARTITIONED
         self._conf = None
         self._roi = None
         self._ctx = None
@@ -162,7 +164,7 @@ class DisparityWLSFilter:
 
     def params_struct(self):
         return WlsParams(self._lambda, self._sigma, 0.25, self._roll_off, self._min_disp, self._num_disp, self._radius,
-                         self._lrc, 3, 0)
+                         self._lrc, 3, int(self.solver))
 
     def filter(self, disparity_map_left, left_view, filtered_disparity_map=None, disparity_map_right=None):
         if disparity_map_right is None:

@@ -213,8 +213,10 @@ typedef struct r3d_wls_params {
     int32_t discontinuity_radius;  /* ceil(0.5*blockSize) for an SGBM matcher */
     int32_t lrc_thresh;            /* 24 (1.5 px in x16 units) */
     int32_t num_iter;              /* 3 */
-    int32_t reserved;
+    int32_t solver;                /* R3D_WLS_SOLVER_*: how the smoother's tridiagonal systems are solved */
 } r3d_wls_params;
+#define R3D_WLS_SOLVER_PARTITIONED 0 /* block-parallel (31-unknown blocks + Schur complement over separators); default */
+#define R3D_WLS_SOLVER_SEQUENTIAL 1  /* one Thomas sweep per line, the operation order of the CPU original; slow */
 /* disp_left / disp_right: int16 x16 maps of the left and the right matcher (the right one holds negative values);
  * guide: uint8 left view with guide_cn = 1 or 3 channels.  out: int16 x16, 16*(minD-1) outside the ROI.
  * confidence (may be NULL): float [h][w] map in [0,255] (getConfidenceMap()). */

@@ -107,22 +107,24 @@ def _disparities(r3d, L, R, D, bs=5):
     return left.compute(L, R), right.compute(R, L), wls
 
 
-@pytest.mark.parametrize("W,H,D,guide_cn", [(333, 121, 32, 1), (640, 200, 64, 1), (257, 190, 48, 3)])
+@pytest.mark.parametrize("W,H,D,guide_cn", [(333, 121, 32, 1), (640, 200, 64, 1), (257, 190, 48, 3), (95, 33, 16, 1), (160, 64, 32, 1)])
 def test_wls_filter_vs_oracle(r3d, synth, W, H, D, guide_cn):
-    """float32 pipeline with one fixed operation order on both sides: confidence map equal to 1e-3 (absolute, range
-    0..255), filtered disparity equal up to one LSB (1/16 px) on at most 0.1 % of the pixels."""
+    """float32 pipeline.  Sequential solver (the oracle's operation order): confidence and output identical.  Default
+    block-partitioned solver (same systems, different rounding): filtered disparity equal up to one LSB (1/16 px) on
+    at most 0.1 % of the pixels."""
     L, R, _ = synth.stereo_pair(W, H, D, seed=W)
     dl, dr, wls = _disparities(r3d, L, R, D)
     wls.setLambda(8000)
     wls.setSigmaColor(1.5)
     guide = L if guide_cn == 1 else np.stack([L, np.roll(L, 1, 1), L[::-1]], -1).copy()
-    got = wls.filter(dl, guide, None, dr)
     want, wconf = _po().wls_filter(dl, guide, dr, 0, D, 5, lam=8000, sigma_color=1.5, return_confidence=True)
-    np.testing.assert_allclose(wls.getConfidenceMap(), wconf, atol=1e-3)
+    got = wls.filter(dl, guide, None, dr)
+    np.testing.assert_array_equal(wls.getConfidenceMap(), wconf)
     diff = np.abs(got.astype(int) - want.astype(int))
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
     assert (got[:, :D] == -16).all() and got.dtype == np.int16 and wls.getROI() == (D, 0, W - D, H)
-    assert (got[:, D:] >= -16).all()
+    wls.solver = r3d.stereo_prepost.SOLVER_SEQUENTIAL
+    np.testing.assert_array_equal(wls.filter(dl, guide, None, dr), want)
 
 
 def test_wls_negative_min_disparity_roi_and_accessors(r3d, synth):
