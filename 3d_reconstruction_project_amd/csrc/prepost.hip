@@ -123,16 +123,31 @@ __global__ void k_minmax_init(int *mm) { mm[0] = 2147483647; mm[1] = -2147483647
 
 __global__ void k_minmax_s16(const int16_t *__restrict__ a, int64_t n, int *mm) {
     int lo = 32767, hi = -32768;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int v = a[i];
-        lo = min(lo, v);
-        hi = max(hi, v);
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+    const int64_t head = std::min<int64_t>(n, (int64_t)((16 - ((uintptr_t)a & 15)) & 15) / 2);  // elements before 16-B alignment
+    const int64_t nv = (n - head) / 8;
+    const int4 *v = (const int4 *)(a + head);
+    for (int64_t i = tid; i < nv; i += nth) {
+        const int4 q = v[i];
+        const int w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int e0 = (int)(int16_t)(w[j] & 0xffff), e1 = w[j] >> 16;
+            lo = min(lo, min(e0, e1));
+            hi = max(hi, max(e0, e1));
+        }
     }
+    for (int64_t i = tid; i < head; i += nth) { lo = min(lo, (int)a[i]); hi = max(hi, (int)a[i]); }
+    for (int64_t i = head + nv * 8 + tid; i < n; i += nth) { lo = min(lo, (int)a[i]); hi = max(hi, (int)a[i]); }
     for (int o = 32; o; o >>= 1) {
         lo = min(lo, __shfl_xor(lo, o));
         hi = max(hi, __shfl_xor(hi, o));
     }
-    if ((threadIdx.x & 63) == 0) {
+    __shared__ int slo[4], shi[4];  // one global atomic pair per workgroup: same-address atomics serialise at the memory side
+    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) { lo = min(lo, slo[w]); hi = max(hi, shi[w]); }
         atomicMin(&mm[0], lo);
         atomicMax(&mm[1], hi);
     }
@@ -161,25 +176,72 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 // depth-discontinuity confidence of one view inside its ROI [x0, x0+rw): 1 - roll_off * box-variance of the raw (x16)
 // disparities, clipped at 0; box sums are integers (exact), mean = float(double(sum) * (1/k^2)) like a 32F boxFilter with
 // fp64 accumulators; BORDER_REFLECT_101 at the ROI edge (the ROI is converted into its own matrix first)
-__global__ void k_wls_dd(const int16_t *__restrict__ disp, int W, int H, int x0, int rw, int radius, float roll_off,
-                         float *__restrict__ dd) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= rw || y >= H) return;
-    long long s = 0, s2 = 0;
-    for (int dy = -radius; dy <= radius; dy++) {
-        const int16_t *row = disp + (size_t)reflect101(y + dy, H) * W + x0;
-        for (int dx = -radius; dx <= radius; dx++) {
-            const int v = row[reflect101(x + dx, rw)];
-            s += v;
-            s2 += (long long)v * v;
+#define DD_STRIP 32
+// One wave per 64 columns x 32 rows; RT > 0: compile-time radius (tap loops unroll, loads batch), RT = 0: any radius.  Vertical running sums of horizontal (2r+1)-tap sums (integers: exact in any
+// order); each row's horizontal sums are computed once and parked in an LDS ring of 2r+1 slots until they leave the window.
+template <int RT>
+__global__ __launch_bounds__(64) void k_wls_dd(const int16_t *__restrict__ disp, int W, int H, int x0, int rw, int radius_rt,
+                                               float roll_off, float *__restrict__ dd) {
+    extern __shared__ long long dd_ring[];  // [2r+1][64] sums of squares, then [2r+1][64] int sums
+    const int radius = RT > 0 ? RT : radius_rt;
+    const int k = 2 * radius + 1;
+    long long *ring2 = dd_ring;
+    int *ring1 = (int *)(dd_ring + (size_t)k * 64);
+    const int lane = threadIdx.x, x = blockIdx.x * 64 + lane, ys = blockIdx.y * DD_STRIP;
+    const bool live = x < rw;
+    const int xc = min(x, rw - 1);
+    const bool inner = xc - radius >= 0 && xc + radius < rw;
+    auto hsum = [&](int yy, int &s, long long &s2) {
+        const int16_t *row = disp + (size_t)reflect101(yy, H) * W + x0;
+        int a = 0;
+        long long a2 = 0;
+        if (inner) {
+#pragma unroll
+            for (int dx = -radius; dx <= radius; dx++) {
+                const int v = row[xc + dx];
+                a += v;
+                a2 += (long long)(v * v);
+            }
+        } else {
+#pragma unroll
+            for (int dx = -radius; dx <= radius; dx++) {
+                const int v = row[reflect101(xc + dx, rw)];
+                a += v;
+                a2 += (long long)(v * v);
+            }
+        }
+        s = a;
+        s2 = a2;
+    };
+    long long S = 0, S2 = 0;
+    for (int i = 0; i < k; i++) {  // rows ys-r .. ys+r; ring slot of row yy is (yy - (ys - r)) mod k
+        int s;
+        long long s2;
+        hsum(ys - radius + i, s, s2);
+        ring1[i * 64 + lane] = s;
+        ring2[i * 64 + lane] = s2;
+        S += s;
+        S2 += s2;
+    }
+    const double sc = 1.0 / (double)(k * k);
+    const int ye = min(ys + DD_STRIP, H);
+    int slot = 0;  // slot of the oldest row (y - r)
+    for (int y = ys; y < ye; y++) {
+        const float mean = (float)((double)S * sc), sq = (float)((double)S2 * sc);
+        const float var = sq - mean * mean;
+        const float v = 1.0f - roll_off * var;
+        if (live) dd[(size_t)y * W + x0 + x] = v > 0.f ? v : 0.f;
+        if (y + 1 < ye) {
+            int s;
+            long long s2;
+            hsum(y + radius + 1, s, s2);
+            S += s - ring1[slot * 64 + lane];
+            S2 += s2 - ring2[slot * 64 + lane];
+            ring1[slot * 64 + lane] = s;
+            ring2[slot * 64 + lane] = s2;
+            slot = slot + 1 == k ? 0 : slot + 1;
         }
     }
-    const int k = 2 * radius + 1;
-    const double sc = 1.0 / (double)(k * k);
-    const float mean = (float)((double)s * sc), sq = (float)((double)s2 * sc);
-    const float var = sq - mean * mean;
-    const float v = 1.0f - roll_off * var;
-    dd[(size_t)y * W + x0 + x] = v > 0.f ? v : 0.f;
 }
 
 // LR-consistency confidence over the left ROI, x255; writes the two planes the smoother runs on (ROI-sized, pitch lw):
@@ -420,7 +482,10 @@ __device__ __forceinline__ void tile_load(const float *__restrict__ g, float *t,
         int row, col, o;
         if (VERT) { row = p + i; col = line0 + lane; o = i * 64 + lane; }
         else { row = line0 + 2 * i + (lane >> 5); col = p + (lane & 31); o = (2 * i + (lane >> 5)) * 33 + (lane & 31); }
-        t[o] = (row < H && col < W) ? g[(size_t)row * W + col] : 0.f;
+        // clamped address + bit mask instead of a select: a select gets turned into a branch around the load, and a
+        // branch per load serialises the 96 loads of a tile (one s_waitcnt vmcnt(0) each)
+        const float v = g[(size_t)min(row, H - 1) * W + min(col, W - 1)];
+        t[o] = __int_as_float(__float_as_int(v) & ((row < H && col < W) ? -1 : 0));
     }
 }
 template <bool VERT>
@@ -434,179 +499,292 @@ __device__ __forceinline__ void tile_store(float *__restrict__ g, const float *t
     }
 }
 
-template <bool VERT>
-__global__ __launch_bounds__(64) void k_fgs_pA(const float *__restrict__ C, const float *__restrict__ s0,
-                                               const float *__restrict__ s1, float *__restrict__ rec, int W, int H, float lam) {
-    __shared__ float tC[TILE_F], t0[TILE_F], t1[TILE_F], tv[TILE_F];
-    const int lane = threadIdx.x, k = blockIdx.x, line0 = blockIdx.y * 64;
-    const int N = VERT ? H : W, NL = VERT ? W : H;
-    const int p = k * PT, q = min(p + PT - 1, N), n = q - p;
-    tile_load<VERT>(C, tC, W, H, line0, p, lane);
-    tile_load<VERT>(s0, t0, W, H, line0, p, lane);
-    tile_load<VERT>(s1, t1, W, H, line0, p, lane);
-    __syncthreads();
-    const int line = line0 + lane;
-    if (line >= NL) return;
-    const float cl = p > 0 ? (VERT ? C[(size_t)(p - 1) * W + line] : C[(size_t)line * W + p - 1]) : 0.f;
+// The block solves keep a line's 32 tile values in registers (static indexing, fully unrolled; n = block length is
+// wave-uniform), so that the elimination chain never waits on LDS or memory; one IEEE division per step gives 1/denom,
+// the right-hand sides are multiplied by it.
+struct BlockEnds {
+    float yF1, yL1, yF2, yL2, vF, vL, wF, wL, a_s, c_s, fs1, fs2;
+};
+
+// c[j]: raw weights (c[31]: the separator's), y1/y2: the two signals.  cl = raw weight left of the block.
+// Blocks are always solved at full length: positions past the end of a line hold zero weights and zero data (tile loads
+// pad with 0), which makes them decoupled identity equations (the last real weight of a line is 0 by construction).
+__device__ __forceinline__ void block_solve_A(float (&c)[32], float (&y1)[32], float (&y2)[32], float cl, float lam, BlockEnds &e) {
+    float v[31];
     const float a0 = lam * cl;
-    float cprev = cl, ccprev = 0.f, y1p = 0.f, y2p = 0.f, vp = 0.f, denom = 1.f;
-    for (int j = 0; j < n; j++) {
-        const int i = lidx<VERT>(lane, j);
-        const float craw = tC[i], a = lam * cprev, c = lam * craw;
-        const float diag = (1.0f - a) - c;
-        float y1 = t0[i], y2 = t1[i], v;
-        if (j > 0) {
-            denom = diag - a * ccprev;
-            y1 = (y1 - a * y1p) / denom;
-            y2 = (y2 - a * y2p) / denom;
-            v = (0.f - a * vp) / denom;
-        } else {
-            denom = diag;
-            y1 = y1 / denom;
-            y2 = y2 / denom;
-            v = a0 / denom;
-        }
-        const float cc = j < n - 1 ? c / denom : 0.f;
-        tC[i] = cc;
-        t0[i] = y1;
-        t1[i] = y2;
-        tv[i] = v;
-        cprev = craw; ccprev = cc; y1p = y1; y2p = y2; vp = v;
+    float cprev = cl, ccprev = 0.f, y1p = 0.f, y2p = 0.f, vp = 0.f, rinv = 1.f;
+#pragma unroll
+    for (int j = 0; j < 31; j++) {
+        const float craw = c[j], a = lam * cprev, cj = lam * craw;
+        const float diag = (1.0f - a) - cj;
+        const float denom = j > 0 ? diag - a * ccprev : diag;
+        rinv = 1.0f / denom;
+        y1p = (j > 0 ? y1[j] - a * y1p : y1[j]) * rinv;
+        y2p = (j > 0 ? y2[j] - a * y2p : y2[j]) * rinv;
+        vp = (j > 0 ? 0.f - a * vp : a0) * rinv;
+        ccprev = j < 30 ? cj * rinv : 0.f;
+        c[j] = ccprev;
+        y1[j] = y1p;
+        y2[j] = y2p;
+        v[j] = vp;
+        cprev = craw;
     }
-    const float c_last = lam * cprev;  // coupling of the block's last unknown to its separator (0 when there is none)
-    float y1n = y1p, y2n = y2p, vn = vp, wn = c_last / denom;
-    const float yL1 = y1n, yL2 = y2n, vL = vn, wL = wn;
-    for (int j = n - 2; j >= 0; j--) {
-        const int i = lidx<VERT>(lane, j);
-        const float cc = tC[i];
-        y1n = t0[i] - cc * y1n;
-        y2n = t1[i] - cc * y2n;
-        vn = tv[i] - cc * vn;
+    const float c_last = lam * cprev;  // coupling of the block's last unknown to its separator
+    float wn = c_last * rinv;
+    e.yL1 = y1p; e.yL2 = y2p; e.vL = vp; e.wL = wn;
+#pragma unroll
+    for (int j = 29; j >= 0; j--) {
+        const float cc = c[j];
+        y1p = y1[j] - cc * y1p;
+        y2p = y2[j] - cc * y2p;
+        vp = v[j] - cc * vp;
         wn = 0.f - cc * wn;
     }
-    float a_s = 0.f, c_s = 0.f, fs1 = 0.f, fs2 = 0.f;
-    if (q < N) {  // this block is followed by a separator: unknown q = tile position 31 (untouched above since n = 31)
-        const int i = lidx<VERT>(lane, PT - 1);
-        a_s = c_last;
-        c_s = lam * tC[i];
-        fs1 = t0[i];
-        fs2 = t1[i];
-    }
-    float *r = rec + ((size_t)k * PREC) * NL + line;
-    r[0 * (size_t)NL] = y1n; r[1 * (size_t)NL] = yL1; r[2 * (size_t)NL] = y2n; r[3 * (size_t)NL] = yL2;
-    r[4 * (size_t)NL] = vn;  r[5 * (size_t)NL] = vL;  r[6 * (size_t)NL] = wn;  r[7 * (size_t)NL] = wL;
-    r[8 * (size_t)NL] = a_s; r[9 * (size_t)NL] = c_s; r[10 * (size_t)NL] = fs1; r[11 * (size_t)NL] = fs2;
+    e.yF1 = y1p; e.yF2 = y2p; e.vF = vp; e.wF = wn;
+    e.a_s = c_last;
+    e.c_s = lam * c[31];
+    e.fs1 = y1[31];
+    e.fs2 = y2[31];
 }
 
-// reduced system over the separators of each line; sol[(k*3 + {0: cc, 1: S of signal 0, 2: S of signal 1}) * NL + line]
-__global__ __launch_bounds__(64) void k_fgs_pR(const float *__restrict__ rec, float *__restrict__ sol, int N, int NL) {
+// sl*/sr*: separator values left / right of the block (0 where there is none); result in y1/y2[0..31), separator copied to [31]
+__device__ __forceinline__ void block_solve_B(float (&c)[32], float (&y1)[32], float (&y2)[32], float cl, float lam, float sl1,
+                                              float sl2, float sr1, float sr2) {
+    const float a0 = lam * cl;
+    float cprev = cl, ccprev = 0.f, y1p = 0.f, y2p = 0.f;
+#pragma unroll
+    for (int j = 0; j < 31; j++) {
+        const float craw = c[j], a = lam * cprev, cj = lam * craw;
+        const float diag = (1.0f - a) - cj;
+        const float denom = j > 0 ? diag - a * ccprev : diag;
+        const float rinv = 1.0f / denom;
+        float f1 = y1[j], f2 = y2[j];
+        if (j == 30) {  // coupling to the right separator moves to the right-hand side
+            f1 = f1 - cj * sr1;
+            f2 = f2 - cj * sr2;
+        }
+        y1p = (j > 0 ? f1 - a * y1p : f1 - a0 * sl1) * rinv;
+        y2p = (j > 0 ? f2 - a * y2p : f2 - a0 * sl2) * rinv;
+        ccprev = j < 30 ? cj * rinv : 0.f;
+        c[j] = ccprev;
+        y1[j] = y1p;
+        y2[j] = y2p;
+        cprev = craw;
+    }
+#pragma unroll
+    for (int j = 29; j >= 0; j--) {
+        y1p = y1[j] - c[j] * y1p;
+        y2p = y2[j] - c[j] * y2p;
+        y1[j] = y1p;
+        y2[j] = y2p;
+    }
+    y1[31] = sr1;
+    y2[31] = sr2;
+}
+
+template <bool VERT>
+__device__ __forceinline__ float left_weight(const float *__restrict__ C, int W, int p, int line) {
+    return p > 0 ? (VERT ? C[(size_t)(p - 1) * W + line] : C[(size_t)line * W + p - 1]) : 0.f;
+}
+
+// horizontal pass, phase A: tiles transposed through LDS (coalesced 128-B row segments), then one row per lane
+__global__ __launch_bounds__(64) void k_fgs_hA(const float *__restrict__ C, const float *__restrict__ s0, const float *__restrict__ s1,
+                                               float *__restrict__ rec, int W, int H, float lam) {
+    __shared__ float tC[TILE_F], t0[TILE_F], t1[TILE_F];
+    const int lane = threadIdx.x, k = blockIdx.x, line0 = blockIdx.y * 64;
+    const int p = k * PT;
+    tile_load<false>(C, tC, W, H, line0, p, lane);
+    tile_load<false>(s0, t0, W, H, line0, p, lane);
+    tile_load<false>(s1, t1, W, H, line0, p, lane);
+    __syncthreads();
+    const int line = line0 + lane;
+    if (line >= H) return;
+    float c[32], y1[32], y2[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) { c[j] = tC[lane * 33 + j]; y1[j] = t0[lane * 33 + j]; y2[j] = t1[lane * 33 + j]; }
+    BlockEnds e;
+    block_solve_A(c, y1, y2, left_weight<false>(C, W, p, line), lam, e);
+    float *r = rec + ((size_t)k * PREC) * H + line;
+    const size_t NL = H;
+    r[0 * NL] = e.yF1; r[1 * NL] = e.yL1; r[2 * NL] = e.yF2; r[3 * NL] = e.yL2; r[4 * NL] = e.vF; r[5 * NL] = e.vL;
+    r[6 * NL] = e.wF; r[7 * NL] = e.wL; r[8 * NL] = e.a_s; r[9 * NL] = e.c_s; r[10 * NL] = e.fs1; r[11 * NL] = e.fs2;
+}
+
+// vertical pass, phase A: one column per lane, the 32 rows of the block straight from global memory into registers
+__global__ __launch_bounds__(64) void k_fgs_vA(const float *__restrict__ C, const float *__restrict__ s0, const float *__restrict__ s1,
+                                               float *__restrict__ rec, int W, int H, float lam) {
+    const int k = blockIdx.x, line = blockIdx.y * 64 + threadIdx.x;
+    const int p = k * PT;
+    if (line >= W) return;
+    float c[32], y1[32], y2[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        const int m = p + j < H ? -1 : 0;
+        const size_t o = (size_t)min(p + j, H - 1) * W + line;  // clamped address + bit mask, see tile_load
+        c[j] = __int_as_float(__float_as_int(C[o]) & m);
+        y1[j] = __int_as_float(__float_as_int(s0[o]) & m);
+        y2[j] = __int_as_float(__float_as_int(s1[o]) & m);
+    }
+    BlockEnds e;
+    block_solve_A(c, y1, y2, left_weight<true>(C, W, p, line), lam, e);
+    float *r = rec + ((size_t)k * PREC) * W + line;
+    const size_t NL = W;
+    r[0 * NL] = e.yF1; r[1 * NL] = e.yL1; r[2 * NL] = e.yF2; r[3 * NL] = e.yL2; r[4 * NL] = e.vF; r[5 * NL] = e.vL;
+    r[6 * NL] = e.wF; r[7 * NL] = e.wL; r[8 * NL] = e.a_s; r[9 * NL] = e.c_s; r[10 * NL] = e.fs1; r[11 * NL] = e.fs2;
+}
+
+// coefficients of the reduced (separator) system, one thread per (line, separator):
+//   coef[(k*5 + {ra, rb, rc, r1, r2}) * NL + line]
+__global__ void k_fgs_pRc(const float *__restrict__ rec, float *__restrict__ coef, int N, int NL) {
+    const int line = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (line >= NL) return;
+    const int nb = (N + PT - 1) / PT;
+    const size_t L = NL;
+    const float *r = rec + ((size_t)k * PREC) * L + line;
+    const float a_s = r[8 * L], c_s = r[9 * L];
+    float r1 = r[10 * L] - a_s * r[1 * L], r2 = r[11 * L] - a_s * r[3 * L];
+    const float ra = 0.f - a_s * r[5 * L];
+    float rb = ((1.0f - a_s) - c_s) - a_s * r[7 * L], rc = 0.f;
+    if (k + 1 < nb) {
+        const float *rn = r + (size_t)PREC * L;
+        rb = rb - c_s * rn[4 * L];
+        rc = 0.f - c_s * rn[6 * L];
+        r1 = r1 - c_s * rn[0 * L];
+        r2 = r2 - c_s * rn[2 * L];
+    }
+    float *o = coef + ((size_t)k * 5) * L + line;
+    o[0] = ra; o[L] = rb; o[2 * L] = rc; o[3 * L] = r1; o[4 * L] = r2;
+}
+
+// reduced tridiagonal system over the separators of each line (one lane per line, P = N/32 unknowns);
+// sol[(k*3 + {0: cc, 1: S of signal 0, 2: S of signal 1}) * NL + line].  Loads run one chunk of 8 steps ahead of the chain.
+#define RCH 8
+__global__ __launch_bounds__(64) void k_fgs_pR(const float *__restrict__ coef, float *__restrict__ sol, int N, int NL) {
     const int line = blockIdx.x * 64 + threadIdx.x;
     if (line >= NL) return;
-    const int P = N / PT, nb = (N + PT - 1) / PT;
+    const int P = N / PT;
+    const size_t L = NL;
+    float cur[RCH][5], nxt[RCH][5];
+    auto load = [&](int k0, float (&d)[RCH][5]) {
+#pragma unroll
+        for (int i = 0; i < RCH; i++)
+#pragma unroll
+            for (int f = 0; f < 5; f++) d[i][f] = coef[((size_t)min(k0 + i, P - 1) * 5 + f) * L + line];  // clamped, never a branch
+    };
     float ccprev = 0.f, s1p = 0.f, s2p = 0.f;
-#pragma unroll 4
-    for (int k = 0; k < P; k++) {
-        const float *r = rec + ((size_t)k * PREC) * NL + line;
-        const float yL1 = r[1 * (size_t)NL], yL2 = r[3 * (size_t)NL], vL = r[5 * (size_t)NL], wL = r[7 * (size_t)NL];
-        const float a_s = r[8 * (size_t)NL], c_s = r[9 * (size_t)NL];
-        float r1 = r[10 * (size_t)NL] - a_s * yL1, r2 = r[11 * (size_t)NL] - a_s * yL2;
-        const float ra = 0.f - a_s * vL;
-        float rb = ((1.0f - a_s) - c_s) - a_s * wL, rc = 0.f;
-        if (k + 1 < nb) {
-            const float *rn = r + (size_t)PREC * NL;
-            rb = rb - c_s * rn[4 * (size_t)NL];
-            rc = 0.f - c_s * rn[6 * (size_t)NL];
-            r1 = r1 - c_s * rn[0 * (size_t)NL];
-            r2 = r2 - c_s * rn[2 * (size_t)NL];
+    load(0, cur);
+    for (int k0 = 0; k0 < P; k0 += RCH) {
+        if (k0 + RCH < P) load(k0 + RCH, nxt);
+#pragma unroll
+        for (int i = 0; i < RCH; i++) {
+            if (k0 + i < P) {
+                const float ra = cur[i][0], denom = cur[i][1] - ra * ccprev, rinv = 1.0f / denom;
+                ccprev = cur[i][2] * rinv;
+                s1p = (cur[i][3] - ra * s1p) * rinv;
+                s2p = (cur[i][4] - ra * s2p) * rinv;
+                float *o = sol + ((size_t)(k0 + i) * 3) * L + line;
+                o[0] = ccprev; o[L] = s1p; o[2 * L] = s2p;
+            }
         }
-        const float denom = rb - ra * ccprev;
-        ccprev = rc / denom;
-        s1p = (r1 - ra * s1p) / denom;
-        s2p = (r2 - ra * s2p) / denom;
-        float *o = sol + ((size_t)k * 3) * NL + line;
-        o[0] = ccprev;
-        o[(size_t)NL] = s1p;
-        o[2 * (size_t)NL] = s2p;
+#pragma unroll
+        for (int i = 0; i < RCH; i++)
+#pragma unroll
+            for (int f = 0; f < 5; f++) cur[i][f] = nxt[i][f];
     }
-#pragma unroll 4
-    for (int k = P - 2; k >= 0; k--) {
-        float *o = sol + ((size_t)k * 3) * NL + line;
-        const float cc = o[0];
-        s1p = o[(size_t)NL] - cc * s1p;
-        s2p = o[2 * (size_t)NL] - cc * s2p;
-        o[(size_t)NL] = s1p;
-        o[2 * (size_t)NL] = s2p;
+    // back substitution: S[k] -= cc[k]*S[k+1]; the last separator is final already
+    float b[RCH][3], nb3[RCH][3];
+    auto loadb = [&](int khi, float (&d)[RCH][3]) {  // steps khi, khi-1, ...
+#pragma unroll
+        for (int i = 0; i < RCH; i++)
+#pragma unroll
+            for (int f = 0; f < 3; f++) d[i][f] = sol[((size_t)max(khi - i, 0) * 3 + f) * L + line];
+    };
+    loadb(P - 2, b);
+    for (int khi = P - 2; khi >= 0; khi -= RCH) {
+        if (khi - RCH >= 0) loadb(khi - RCH, nb3);
+#pragma unroll
+        for (int i = 0; i < RCH; i++) {
+            if (khi - i >= 0) {
+                s1p = b[i][1] - b[i][0] * s1p;
+                s2p = b[i][2] - b[i][0] * s2p;
+                float *o = sol + ((size_t)(khi - i) * 3) * L + line;
+                o[L] = s1p; o[2 * L] = s2p;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RCH; i++)
+#pragma unroll
+            for (int f = 0; f < 3; f++) b[i][f] = nb3[i][f];
     }
 }
 
 template <bool VERT>
-__global__ __launch_bounds__(64) void k_fgs_pB(const float *__restrict__ C, float *__restrict__ s0, float *__restrict__ s1,
+__device__ __forceinline__ void sep_values(const float *__restrict__ sol, int k, bool has_sep, int NL, int line, float &sl1, float &sl2,
+                                           float &sr1, float &sr2) {
+    sl1 = sl2 = sr1 = sr2 = 0.f;
+    const size_t L = NL;
+    if (k > 0) {
+        const float *o = sol + ((size_t)(k - 1) * 3) * L + line;
+        sl1 = o[L];
+        sl2 = o[2 * L];
+    }
+    if (has_sep) {
+        const float *o = sol + ((size_t)k * 3) * L + line;
+        sr1 = o[L];
+        sr2 = o[2 * L];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_fgs_hB(const float *__restrict__ C, float *__restrict__ s0, float *__restrict__ s1,
                                                const float *__restrict__ sol, int W, int H, float lam) {
     __shared__ float tC[TILE_F], t0[TILE_F], t1[TILE_F];
     const int lane = threadIdx.x, k = blockIdx.x, line0 = blockIdx.y * 64;
-    const int N = VERT ? H : W, NL = VERT ? W : H;
-    const int p = k * PT, q = min(p + PT - 1, N), n = q - p;
-    tile_load<VERT>(C, tC, W, H, line0, p, lane);
-    tile_load<VERT>(s0, t0, W, H, line0, p, lane);
-    tile_load<VERT>(s1, t1, W, H, line0, p, lane);
+    const int p = k * PT, q = min(p + PT - 1, W);
+    tile_load<false>(C, tC, W, H, line0, p, lane);
+    tile_load<false>(s0, t0, W, H, line0, p, lane);
+    tile_load<false>(s1, t1, W, H, line0, p, lane);
     __syncthreads();
     const int line = line0 + lane;
-    if (line < NL) {
-        const float cl = p > 0 ? (VERT ? C[(size_t)(p - 1) * W + line] : C[(size_t)line * W + p - 1]) : 0.f;
-        float sl1 = 0.f, sl2 = 0.f, sr1 = 0.f, sr2 = 0.f;
-        if (k > 0) {
-            const float *o = sol + ((size_t)(k - 1) * 3) * NL + line;
-            sl1 = o[(size_t)NL];
-            sl2 = o[2 * (size_t)NL];
-        }
-        if (q < N) {
-            const float *o = sol + ((size_t)k * 3) * NL + line;
-            sr1 = o[(size_t)NL];
-            sr2 = o[2 * (size_t)NL];
-        }
-        const float a0 = lam * cl;
-        float cprev = cl, ccprev = 0.f, y1p = 0.f, y2p = 0.f;
-        for (int j = 0; j < n; j++) {
-            const int i = lidx<VERT>(lane, j);
-            const float craw = tC[i], a = lam * cprev, c = lam * craw;
-            const float diag = (1.0f - a) - c;
-            float y1 = t0[i], y2 = t1[i], denom;
-            if (j == n - 1) {  // coupling to the right separator moves to the right-hand side
-                y1 = y1 - c * sr1;
-                y2 = y2 - c * sr2;
-            }
-            if (j > 0) {
-                denom = diag - a * ccprev;
-                y1 = (y1 - a * y1p) / denom;
-                y2 = (y2 - a * y2p) / denom;
-            } else {
-                denom = diag;
-                y1 = (y1 - a0 * sl1) / denom;
-                y2 = (y2 - a0 * sl2) / denom;
-            }
-            const float cc = j < n - 1 ? c / denom : 0.f;
-            tC[i] = cc;
-            t0[i] = y1;
-            t1[i] = y2;
-            cprev = craw; ccprev = cc; y1p = y1; y2p = y2;
-        }
-        for (int j = n - 2; j >= 0; j--) {
-            const int i = lidx<VERT>(lane, j);
-            const float cc = tC[i];
-            y1p = t0[i] - cc * y1p;
-            y2p = t1[i] - cc * y2p;
-            t0[i] = y1p;
-            t1[i] = y2p;
-        }
-        if (q < N) {
-            const int i = lidx<VERT>(lane, PT - 1);
-            t0[i] = sr1;
-            t1[i] = sr2;
-        }
+    if (line < H) {
+        float c[32], y1[32], y2[32];
+#pragma unroll
+        for (int j = 0; j < 32; j++) { c[j] = tC[lane * 33 + j]; y1[j] = t0[lane * 33 + j]; y2[j] = t1[lane * 33 + j]; }
+        float sl1, sl2, sr1, sr2;
+        sep_values<false>(sol, k, q < W, H, line, sl1, sl2, sr1, sr2);
+        block_solve_B(c, y1, y2, left_weight<false>(C, W, p, line), lam, sl1, sl2, sr1, sr2);
+#pragma unroll
+        for (int j = 0; j < 32; j++) { t0[lane * 33 + j] = y1[j]; t1[lane * 33 + j] = y2[j]; }
     }
     __syncthreads();
-    tile_store<VERT>(s0, t0, W, H, line0, p, lane);
-    tile_store<VERT>(s1, t1, W, H, line0, p, lane);
+    tile_store<false>(s0, t0, W, H, line0, p, lane);
+    tile_store<false>(s1, t1, W, H, line0, p, lane);
+}
+
+__global__ __launch_bounds__(64) void k_fgs_vB(const float *__restrict__ C, float *__restrict__ s0, float *__restrict__ s1,
+                                               const float *__restrict__ sol, int W, int H, float lam) {
+    const int k = blockIdx.x, line = blockIdx.y * 64 + threadIdx.x;
+    const int p = k * PT, q = min(p + PT - 1, H);
+    if (line >= W) return;
+    float c[32], y1[32], y2[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        const int m = p + j < H ? -1 : 0;
+        const size_t o = (size_t)min(p + j, H - 1) * W + line;  // clamped address + bit mask, see tile_load
+        c[j] = __int_as_float(__float_as_int(C[o]) & m);
+        y1[j] = __int_as_float(__float_as_int(s0[o]) & m);
+        y2[j] = __int_as_float(__float_as_int(s1[o]) & m);
+    }
+    float sl1, sl2, sr1, sr2;
+    sep_values<true>(sol, k, q < H, W, line, sl1, sl2, sr1, sr2);
+    block_solve_B(c, y1, y2, left_weight<true>(C, W, p, line), lam, sl1, sl2, sr1, sr2);
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        if (p + j < H) {
+            const size_t o = (size_t)(p + j) * W + line;
+            s0[o] = y1[j];
+            s1[o] = y2[j];
+        }
+    }
 }
 
 // out = short(round_half_even(sig0 * (1 / (sig1 + 1e-5)))) inside the ROI, 16*(minD-1) elsewhere
@@ -758,7 +936,7 @@ extern "C" int r3d_normalize_minmax_s16_dev(r3d_ctx *ctx, const int16_t *d_src, 
     const int rc = r3d_reserve(ctx, mmb, 16);
     if (rc) return rc;
     int *mm = (int *)mmb.p;
-    const int nb = (int)std::min<int64_t>((n + 255) / 256, 2048);
+    const int nb = (int)std::min<int64_t>((n + 2047) / 2048, 1024);
     k_minmax_init<<<1, 1, 0, ctx->stream>>>(mm);
     k_minmax_s16<<<nb, 256, 0, ctx->stream>>>(d_src, n, mm);
     k_normalize_s16<<<nb, 256, 0, ctx->stream>>>(d_src, n, mm, std::min(alpha, beta), std::max(alpha, beta), d_dst);
@@ -813,9 +991,23 @@ static int wls_run(r3d_ctx *ctx, PPArena &ar, const r3d_wls_params *p, const int
         ctx->pp_lut_n = nlut;
     }
     const float *lut = (const float *)ctx->pp_lut.p;
-    const dim3 groi((lw + 255) / 256, h);
-    k_wls_dd<<<groi, blk, 0, st>>>(d_dl, w, h, lx, lw, p->discontinuity_radius, (float)p->discontinuity_roll_off, ddl);
-    k_wls_dd<<<groi, blk, 0, st>>>(d_dr, w, h, rx, lw, p->discontinuity_radius, (float)p->discontinuity_roll_off, ddr);
+    const dim3 groi((lw + 255) / 256, h), gdd((lw + 63) / 64, (h + DD_STRIP - 1) / DD_STRIP);
+    const size_t ddsh = (size_t)(2 * p->discontinuity_radius + 1) * 64 * 12;
+    for (int view = 0; view < 2; view++) {
+        const int16_t *dv = view ? d_dr : d_dl;
+        float *out = view ? ddr : ddl;
+        const int vx = view ? rx : lx, r = p->discontinuity_radius;
+        const float ro = (float)p->discontinuity_roll_off;
+        switch (r) {  // radii of blockSize 1..11 (ceil(0.5*bs)) get unrolled tap loops
+            case 1: k_wls_dd<1><<<gdd, 64, ddsh, st>>>(dv, w, h, vx, lw, r, ro, out); break;
+            case 2: k_wls_dd<2><<<gdd, 64, ddsh, st>>>(dv, w, h, vx, lw, r, ro, out); break;
+            case 3: k_wls_dd<3><<<gdd, 64, ddsh, st>>>(dv, w, h, vx, lw, r, ro, out); break;
+            case 4: k_wls_dd<4><<<gdd, 64, ddsh, st>>>(dv, w, h, vx, lw, r, ro, out); break;
+            case 5: k_wls_dd<5><<<gdd, 64, ddsh, st>>>(dv, w, h, vx, lw, r, ro, out); break;
+            case 6: k_wls_dd<6><<<gdd, 64, ddsh, st>>>(dv, w, h, vx, lw, r, ro, out); break;
+            default: k_wls_dd<0><<<gdd, 64, ddsh, st>>>(dv, w, h, vx, lw, r, ro, out); break;
+        }
+    }
     k_wls_conf<<<groi, blk, 0, st>>>(d_dl, d_dr, ddl, ddr, w, h, lx, lw, rx, lw, p->lrc_thresh, s0, s1, d_conf);
     if (gcn == 1) k_fgs_weights<1><<<groi, blk, 0, st>>>(d_guide, gstride, lx, lw, h, lut, ch, cv);
     else k_fgs_weights<3><<<groi, blk, 0, st>>>(d_guide, gstride, lx, lw, h, lut, ch, cv);
@@ -827,18 +1019,24 @@ static int wls_run(r3d_ctx *ctx, PPArena &ar, const r3d_wls_params *p, const int
             lam = lam * (float)p->lambda_attenuation;
         }
     } else {
-        // records and separator solutions of the partitioned solver: 12 + 3 floats per line and block, either direction
-        const int nbh = (lw + PT - 1) / PT, nbv = (h + PT - 1) / PT;
+        // records, reduced-system coefficients and separator solutions: 12 + 5 + 3 floats per line and block
+        const int nbh = (lw + PT - 1) / PT, nbv = (h + PT - 1) / PT, Ph = lw / PT, Pv = h / PT;
         const size_t nrec = std::max((size_t)nbh * h, (size_t)nbv * lw);
-        float *rec = (float *)ar.get(nrec * PREC * 4), *sol = (float *)ar.get(nrec * 3 * 4);
+        float *rec = (float *)ar.get(nrec * PREC * 4), *coef = (float *)ar.get(nrec * 5 * 4), *sol = (float *)ar.get(nrec * 3 * 4);
         if (ar.rc) return ar.rc;
         for (int it = 0; it < p->num_iter; it++) {
-            k_fgs_pA<false><<<dim3(nbh, (h + 63) / 64), 64, 0, st>>>(ch, s0, s1, rec, lw, h, lam);
-            k_fgs_pR<<<(h + 63) / 64, 64, 0, st>>>(rec, sol, lw, h);
-            k_fgs_pB<false><<<dim3(nbh, (h + 63) / 64), 64, 0, st>>>(ch, s0, s1, sol, lw, h, lam);
-            k_fgs_pA<true><<<dim3(nbv, (lw + 63) / 64), 64, 0, st>>>(cv, s0, s1, rec, lw, h, lam);
-            k_fgs_pR<<<(lw + 63) / 64, 64, 0, st>>>(rec, sol, h, lw);
-            k_fgs_pB<true><<<dim3(nbv, (lw + 63) / 64), 64, 0, st>>>(cv, s0, s1, sol, lw, h, lam);
+            k_fgs_hA<<<dim3(nbh, (h + 63) / 64), 64, 0, st>>>(ch, s0, s1, rec, lw, h, lam);
+            if (Ph > 0) {
+                k_fgs_pRc<<<dim3((h + 255) / 256, Ph), 256, 0, st>>>(rec, coef, lw, h);
+                k_fgs_pR<<<(h + 63) / 64, 64, 0, st>>>(coef, sol, lw, h);
+            }
+            k_fgs_hB<<<dim3(nbh, (h + 63) / 64), 64, 0, st>>>(ch, s0, s1, sol, lw, h, lam);
+            k_fgs_vA<<<dim3(nbv, (lw + 63) / 64), 64, 0, st>>>(cv, s0, s1, rec, lw, h, lam);
+            if (Pv > 0) {
+                k_fgs_pRc<<<dim3((lw + 255) / 256, Pv), 256, 0, st>>>(rec, coef, h, lw);
+                k_fgs_pR<<<(lw + 63) / 64, 64, 0, st>>>(coef, sol, h, lw);
+            }
+            k_fgs_vB<<<dim3(nbv, (lw + 63) / 64), 64, 0, st>>>(cv, s0, s1, sol, lw, h, lam);
             lam = lam * (float)p->lambda_attenuation;
         }
     }
