@@ -254,33 +254,56 @@ __device__ __forceinline__ int ceil_div_small(int thr, int a, float inv_a) {
 // ---------------------------------------------------------------------------------------------------------
 // k_prefilter: per pixel, both images: clipped x-Sobel (calcPixelCostBT's `tab` lookup), raw intensity, and the
 // half-pixel min/max intervals of both.  QUIRK: columns 0 and w-1 of both channels read ftzero.
-__device__ __forceinline__ int px_grad(const uint8_t *img, int ld, int W, int H, int x, int y, int ft) {
-    if (x <= 0 || x >= W - 1) return ft;
-    const uint8_t *r = img + (size_t)y * ld, *a = img + (size_t)max(y - 1, 0) * ld, *b = img + (size_t)min(y + 1, H - 1) * ld;
-    int s = ((int)r[x + 1] - (int)r[x - 1]) * 2 + ((int)a[x + 1] - (int)a[x - 1]) + ((int)b[x + 1] - (int)b[x - 1]);
-    return min(max(s, -ft), ft) + ft;
-}
-__device__ __forceinline__ int px_raw(const uint8_t *img, int ld, int W, int x, int y, int ft) {
-    return (x <= 0 || x >= W - 1) ? ft : (int)img[(size_t)y * ld + x];
-}
+// gradient(x, y) = clamp(2*(I[y][x+1]-I[y][x-1]) + (I[y-1][x+1]-I[y-1][x-1]) + (I[y+1][x+1]-I[y+1][x-1]), -ft, ft) + ft with rows
+// clamped to the image; intensity = I[y][x].
 __device__ __forceinline__ void bt_interval(int vm, int v, int vp, bool has_m, bool has_p, int &lo, int &hi) {
     int l = has_m ? (v + vm) / 2 : v, r = has_p ? (v + vp) / 2 : v;
     lo = min(min(l, r), v);
     hi = max(max(l, r), v);
 }
+// One workgroup per 256-pixel column segment and band of PF_ROWS rows: every source row is read once (260 columns incl.
+// halo; a thread keeps the three rows of its column in registers and rolls them), the gradient / intensity pair of 258
+// positions is computed from LDS, and each thread forms its pixel's two intervals from its neighbours' pairs.  All global
+// loads use clamped coordinates (no branch around a load).
+#define PF_ROWS 8
 __global__ void __launch_bounds__(256) k_prefilter(const uint8_t *__restrict__ L, const uint8_t *__restrict__ R, int ld,
                                                    int W, int H, int ft, uint2 *__restrict__ recL, uint2 *__restrict__ recR) {
-    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
+    __shared__ int raw[260];  // rows y-1 | y << 8 | y+1 << 16 at columns x0-2 .. x0+257
+    __shared__ int gi[258];   // gradient | intensity << 8 at columns x0-1 .. x0+256
+    const int t = threadIdx.x, x0 = blockIdx.x * 256, yb = blockIdx.y * PF_ROWS;
     const uint8_t *img = blockIdx.z == 0 ? L : R;
     uint2 *rec = blockIdx.z == 0 ? recL : recR;
+    const int xc = min(max(x0 - 2 + t, 0), W - 1), xe = min(max(x0 + 254 + (t & 3), 0), W - 1);
+    auto px = [&](int yy, int xx) { return (int)img[(size_t)min(max(yy, 0), H - 1) * ld + xx]; };
+    int a = px(yb - 1, xc), r = px(yb, xc), ae = px(yb - 1, xe), re = px(yb, xe);
+    const int x = x0 + t;
     const bool hm = x > 0, hp = x < W - 1;
-    int gm = hm ? px_grad(img, ld, W, H, x - 1, y, ft) : 0, g = px_grad(img, ld, W, H, x, y, ft), gp = hp ? px_grad(img, ld, W, H, x + 1, y, ft) : 0;
-    int im = hm ? px_raw(img, ld, W, x - 1, y, ft) : 0, i = px_raw(img, ld, W, x, y, ft), ip = hp ? px_raw(img, ld, W, x + 1, y, ft) : 0;
-    int g0, g1, i0, i1;
-    bt_interval(gm, g, gp, hm, hp, g0, g1);
-    bt_interval(im, i, ip, hm, hp, i0, i1);
-    rec[(size_t)y * W + x] = make_uint2((unsigned)g | (g0 << 8) | (g1 << 16) | (i << 24), (unsigned)i0 | (i1 << 8));
+    for (int y = yb; y < min(yb + PF_ROWS, H); y++) {
+        const int b = px(y + 1, xc), be = px(y + 1, xe);
+        raw[t] = a | (r << 8) | (b << 16);
+        if (t < 4) raw[256 + t] = ae | (re << 8) | (be << 16);
+        a = r; r = b; ae = re; re = be;
+        __syncthreads();
+        auto pair_at = [&](int j) {  // j: index into gi, column x0-1+j, raw index of that column = j+1
+            const int xx = x0 - 1 + j;
+            const int m = raw[j], c = raw[j + 1], p = raw[j + 2];
+            const int s = (((p >> 8) & 255) - ((m >> 8) & 255)) * 2 + ((p & 255) - (m & 255)) + (((p >> 16) & 255) - ((m >> 16) & 255));
+            int g = min(max(s, -ft), ft) + ft, i = (c >> 8) & 255;
+            if (xx <= 0 || xx >= W - 1) { g = ft; i = ft; }
+            gi[j] = g | (i << 8);
+        };
+        pair_at(t);
+        if (t < 2) pair_at(256 + t);
+        __syncthreads();
+        if (x < W) {
+            const int vm = gi[t], v = gi[t + 1], vp = gi[t + 2];
+            int g0, g1, i0, i1;
+            const int g = v & 255, i = v >> 8;
+            bt_interval(vm & 255, g, vp & 255, hm, hp, g0, g1);
+            bt_interval(vm >> 8, i, vp >> 8, hm, hp, i0, i1);
+            rec[(size_t)y * W + x] = make_uint2((unsigned)g | (g0 << 8) | (g1 << 16) | (i << 24), (unsigned)i0 | (i1 << 8));
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1474,7 +1497,7 @@ __global__ void __launch_bounds__(64) k_selftest(int *out) {
 // k_streambench (diagnostic, not on the product path): every wave streams through its own `row_bytes`-long row,
 // MODE 0: 4 B/lane requests (256 B per wave-instruction, the access shape of k_hscan), MODE 1: 16 B/lane (1 KB);
 // `write` adds a store of the same shape to a second buffer.  Used to price access shapes.
-template <int MODE>
+template <int MODE, int NTL, int NTS>
 __global__ void __launch_bounds__(64) k_streambench(const int *__restrict__ in, int *__restrict__ out, size_t row_words, int write, int delay) {
     const int lane = threadIdx.x;
     const int *r = in + (size_t)blockIdx.x * row_words;
@@ -1484,24 +1507,36 @@ __global__ void __launch_bounds__(64) k_streambench(const int *__restrict__ in, 
         for (size_t x = 0; x + 64 * 16 <= row_words; x += 64 * 16) {
             int v[16];
 #pragma unroll
-            for (int u = 0; u < 16; u++) v[u] = r[x + u * 64 + lane];
+            for (int u = 0; u < 16; u++) v[u] = NTL ? __builtin_nontemporal_load(&r[x + u * 64 + lane]) : r[x + u * 64 + lane];
 #pragma unroll
             for (int u = 0; u < 16; u++) {
                 acc += v[u];
                 for (int d = 0; d < delay; d++) acc = __builtin_amdgcn_update_dpp(acc, acc, 0xB1, 0xf, 0xf, false) + 1;
-                if (write) o[x + u * 64 + lane] = acc;
+                if (write) {
+                    if (NTS) __builtin_nontemporal_store(acc, &o[x + u * 64 + lane]);
+                    else o[x + u * 64 + lane] = acc;
+                }
             }
         }
     } else {
+        typedef int v4i __attribute__((ext_vector_type(4)));
         for (size_t x = 0; x + 256 * 4 <= row_words; x += 256 * 4) {
-            int4 v[4];
+            v4i v[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = *(const int4 *)&r[x + u * 256 + lane * 4];
+            for (int u = 0; u < 4; u++) {
+                const v4i *q = (const v4i *)&r[x + u * 256 + lane * 4];
+                v[u] = NTL ? __builtin_nontemporal_load(q) : *q;
+            }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 acc += v[u].x + v[u].y + v[u].z + v[u].w;
                 for (int d = 0; d < 4 * delay; d++) acc = __builtin_amdgcn_update_dpp(acc, acc, 0xB1, 0xf, 0xf, false) + 1;
-                if (write) *(int4 *)&o[x + u * 256 + lane * 4] = make_int4(acc, acc, acc, acc);
+                if (write) {
+                    const v4i w4 = {acc, acc, acc, acc};
+                    v4i *q = (v4i *)&o[x + u * 256 + lane * 4];
+                    if (NTS) __builtin_nontemporal_store(w4, q);
+                    else *q = w4;
+                }
             }
         }
     }
@@ -1621,8 +1656,19 @@ int r3d_streambench_run(r3d_ctx *ctx, int mode, int rows, size_t row_bytes, int 
     R3D_HIP(ctx, hipEventCreate(&b));
     for (int i = 0; i < reps + 1; i++) {
         if (i == 1) R3D_HIP(ctx, hipEventRecord(a, ctx->stream));
-        if (mode == 0) k_streambench<0><<<rows, 64, 0, ctx->stream>>>((const int *)ctx->ws[0].cost.p, (int *)ctx->ws[0].hsum.p, row_words, write, delay);
-        else k_streambench<1><<<rows, 64, 0, ctx->stream>>>((const int *)ctx->ws[0].cost.p, (int *)ctx->ws[0].hsum.p, row_words, write, delay);
+        const int *in = (const int *)ctx->ws[0].cost.p;
+        int *out = (int *)ctx->ws[0].hsum.p;
+        // mode bit 0: request shape, bit 1: non-temporal loads, bit 2: non-temporal stores
+        switch (mode & 7) {
+            case 0: k_streambench<0, 0, 0><<<rows, 64, 0, ctx->stream>>>(in, out, row_words, write, delay); break;
+            case 1: k_streambench<1, 0, 0><<<rows, 64, 0, ctx->stream>>>(in, out, row_words, write, delay); break;
+            case 2: k_streambench<0, 1, 0><<<rows, 64, 0, ctx->stream>>>(in, out, row_words, write, delay); break;
+            case 3: k_streambench<1, 1, 0><<<rows, 64, 0, ctx->stream>>>(in, out, row_words, write, delay); break;
+            case 4: k_streambench<0, 0, 1><<<rows, 64, 0, ctx->stream>>>(in, out, row_words, write, delay); break;
+            case 5: k_streambench<1, 0, 1><<<rows, 64, 0, ctx->stream>>>(in, out, row_words, write, delay); break;
+            case 6: k_streambench<0, 1, 1><<<rows, 64, 0, ctx->stream>>>(in, out, row_words, write, delay); break;
+            default: k_streambench<1, 1, 1><<<rows, 64, 0, ctx->stream>>>(in, out, row_words, write, delay); break;
+        }
     }
     R3D_HIP(ctx, hipEventRecord(b, ctx->stream));
     R3D_HIP(ctx, hipEventSynchronize(b));
@@ -1686,7 +1732,7 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
     r3d_prof_begin(ctx, ws);
 
     r3d_prof_mark(ctx, ws, st, "prefilter");
-    k_prefilter<<<dim3((w + 255) / 256, h, 2), 256, 0, st>>>(d_left, d_right, stride, w, h, g.ftzero, (uint2 *)ws.rec_l.p, (uint2 *)ws.rec_r.p);
+    k_prefilter<<<dim3((w + 255) / 256, (h + PF_ROWS - 1) / PF_ROWS, 2), 256, 0, st>>>(d_left, d_right, stride, w, h, g.ftzero, (uint2 *)ws.rec_l.p, (uint2 *)ws.rec_r.p);
     R3D_HIP(ctx, hipGetLastError());
 
     // implementation generations kept side by side for A/B measurements: R3D_SGM_IMPL = v1 | v2 (default) | v3.
