@@ -66,8 +66,23 @@ __global__ void __launch_bounds__(256) k_cell_keys(const double *__restrict__ p,
         cx = cell_coord(p[i * 3], ox, inv); cy = cell_coord(p[i * 3 + 1], oy, inv); cz = cell_coord(p[i * 3 + 2], oz, inv);
     }
     cx = min(max(cx, 0), nx - 1); cy = min(max(cy, 0), ny - 1); cz = min(max(cz, 0), nz - 1);
-    // key_order 0: x fastest (search grid); 1: z fastest (voxel output in lexicographic (kx,ky,kz) order)
-    unsigned long long k = key_order == 0 ? ((unsigned long long)cz * ny + cy) * nx + cx : ((unsigned long long)cx * ny + cy) * nz + cz;
+    // key_order 0: x fastest (search grid); 1: z fastest (voxel output in lexicographic (kx,ky,kz) order);
+    // 2: Morton code of the cell coordinates (query ordering: consecutive points stay compact in all three axes)
+    unsigned long long k;
+    if (key_order == 2) {
+        auto spread = [](unsigned long long v) {  // 21 bits -> every third bit
+            v &= 0x1fffffull;
+            v = (v | v << 32) & 0x1f00000000ffffull;
+            v = (v | v << 16) & 0x1f0000ff0000ffull;
+            v = (v | v << 8) & 0x100f00f00f00f00full;
+            v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+            v = (v | v << 2) & 0x1249249249249249ull;
+            return v;
+        };
+        k = spread((unsigned long long)cx) | spread((unsigned long long)cy) << 1 | spread((unsigned long long)cz) << 2;
+    } else {
+        k = key_order == 0 ? ((unsigned long long)cz * ny + cy) * nx + cx : ((unsigned long long)cx * ny + cy) * nz + cz;
+    }
     keys[i] = k;
     vals[i] = (int)i;
 }
@@ -404,8 +419,47 @@ __global__ void __launch_bounds__(ICP_BLOCK) k_icp_eval(GridView g, const double
             }
         };
         for (int s = 1; s <= max(smax, 1); s++) {
-            if (s == 1) for_block3(g, cx, cy, cz, visit);      // shells 0 and 1 as nine contiguous runs
-            else for_shell(g, cx, cy, cz, s, visit);
+            if (s == 1) {
+                // shells 0 and 1 as nine contiguous runs.  All 18 run bounds are requested before any is used, and the
+                // candidates of a run are fetched four at a time (clamped index, no branch around a load): the search is
+                // a chain of dependent gathers otherwise, one L1/L2 round trip per candidate.
+                const int xa = cx - 1, xb = cx + 1;
+                const bool xok = xb >= 0 && xa <= g.nx - 1;
+                const int x0 = min(max(xa, 0), g.nx - 1), x1 = min(max(xb, 0), g.nx - 1);
+                int rb[9], re[9];
+#pragma unroll
+                for (int r = 0; r < 9; r++) {
+                    const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+                    const bool ok = xok && z >= 0 && z < g.nz && y >= 0 && y < g.ny;
+                    const int64_t row = ((int64_t)min(max(z, 0), g.nz - 1) * g.ny + min(max(y, 0), g.ny - 1)) * g.nx;
+                    const int b = g.cstart[row + x0], e = g.cstart[row + x1 + 1];
+                    rb[r] = b;
+                    re[r] = b + ((e - b) & (ok ? -1 : 0));
+                }
+#pragma unroll
+                for (int r = 0; r < 9; r++) {
+                    const int e = re[r];
+                    for (int j0 = rb[r]; j0 < e; j0 += 4) {
+                        double X[4], Y[4], Z[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int64_t jj = min(j0 + u, e - 1);
+                            X[u] = g.pts[jj * 3]; Y[u] = g.pts[jj * 3 + 1]; Z[u] = g.pts[jj * 3 + 2];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int j = j0 + u;
+                            const double dx = X[u] - px, dy = Y[u] - py, dz = Z[u] - pz;
+                            const double d2 = dx * dx + dy * dy + dz * dz;
+                            if (j < e && d2 <= best) {
+                                if (d2 < best || (bi >= 0 && g.idx[j] < g.idx[bi])) { best = d2; bi = j; }
+                            }
+                        }
+                    }
+                }
+            } else {
+                for_shell(g, cx, cy, cz, s, visit);
+            }
             const double reach = s * g.cell;
             if (bi >= 0 && best <= reach * reach) break;
         }
@@ -582,9 +636,15 @@ int sort_by_cell(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, con
     const int nb = (int)((n + 255) / 256);
     k_cell_keys<<<nb, 256, 0, ctx->stream>>>(d_pts, n, org[0], org[1], org[2], cell, dims[0], dims[1], dims[2], key_order, k0, v0);
     R3D_HIP(ctx, hipGetLastError());
-    const unsigned long long maxkey = (unsigned long long)dims[0] * dims[1] * dims[2];
     int bits = 1;
-    while (bits < 64 && (maxkey >> bits)) bits++;
+    if (key_order == 2) {
+        int m = std::max(dims[0], std::max(dims[1], dims[2])), b1 = 1;
+        while ((1 << b1) < m) b1++;
+        bits = std::min(63, 3 * b1);
+    } else {
+        const unsigned long long maxkey = (unsigned long long)dims[0] * dims[1] * dims[2];
+        while (bits < 64 && (maxkey >> bits)) bits++;
+    }
     size_t tb = 0;
     R3D_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k0, k1, v0, v1, (int)n, 0, bits, ctx->stream));
     void *tmp = ar.get(tb);
@@ -1066,8 +1126,8 @@ int r3d_icp(r3d_ctx *ctx, const r3d_icp_params *p, const double *src, int64_t ns
         if (ar.rc) return ar.rc;
         k_gather3<<<(unsigned)((nt + 255) / 256), 256, 0, ctx->stream>>>(d_tn, G.v.idx, nt, d_tns);
     }
-    // spatially sort the source once (by target-grid cell of its initial pose) so that neighbouring threads walk the
-    // same cells; sums are order-dependent only at the 1e-16 level and stay deterministic
+    // spatially sort the source once (Morton order of the target-grid cell of its initial pose) so that neighbouring threads
+    // walk the same cells; sums are order-dependent only at the 1e-16 level and stay deterministic
     double T[16];
     if (init4x4) memcpy(T, init4x4, sizeof T);
     else for (int i = 0; i < 16; i++) T[i] = (i % 5 == 0);
@@ -1078,7 +1138,7 @@ int r3d_icp(r3d_ctx *ctx, const r3d_icp_params *p, const double *src, int64_t ns
         int dims[3] = {G.v.nx, G.v.ny, G.v.nz};
         unsigned long long *sk;
         int *sidx;
-        if ((rc = sort_by_cell(ctx, ar, d_s0, ns, G.mn, G.v.cell, dims, 0, &sk, &sidx))) return rc;
+        if ((rc = sort_by_cell(ctx, ar, d_s0, ns, G.mn, G.v.cell, dims, 2, &sk, &sidx))) return rc;
         double *d_ss = (double *)ar.get((size_t)ns * 24);
         if (ar.rc) return ar.rc;
         k_gather3<<<(unsigned)((ns + 255) / 256), 256, 0, ctx->stream>>>(d_s, sidx, ns, d_ss);
