@@ -74,6 +74,59 @@ def bench_gicp(r3d, ctx, n=1_000_000, iters=20, cpu=True):
     return out
 
 
+def bench_frame_loop(r3d, ctx, dL, dR, reps=5):
+    """Informational: one iteration of the Calib_depth/depth2.py:243-257 frame loop at C2 size, everything resident in
+    HBM: remap + grey (x2), left and right matcher, WLS filter, normalize.  Fixed-point identity-plus-fraction maps keep the
+    rectified pair a valid stereo pair."""
+    import ctypes
+    import numpy as np
+    vp = ctypes.c_void_p
+    xs, ys = np.meshgrid(np.arange(W, dtype=np.int16), np.arange(H, dtype=np.int16))
+    d_m1 = ctx.to_device(np.ascontiguousarray(np.stack([xs, ys], -1)))
+    d_m2 = ctx.to_device(np.full((H, W), 5 * 32 + 7, np.uint16))
+    bufs = [d_m1, d_m2]
+
+    def alloc(n):
+        bufs.append(ctx.alloc(n))
+        return bufs[-1]
+    hL, hR = np.empty((H, W), np.uint8), np.empty((H, W), np.uint8)
+    ctx.d2h(hL, dL)
+    ctx.d2h(hR, dR)
+    d_fl = ctx.to_device(np.ascontiguousarray(np.stack([hL] * 3, -1)))
+    d_fr = ctx.to_device(np.ascontiguousarray(np.stack([hR] * 3, -1)))
+    bufs += [d_fl, d_fr]
+    d_rl, d_rr, d_gl, d_gr = alloc(W * H * 3), alloc(W * H * 3), alloc(W * H), alloc(W * H)
+    d_dl, d_dr, d_f, d_n = (alloc(W * H * 2) for _ in range(4))
+    left = r3d.reference_matcher(numDisparities=D, blockSize=5)
+    right = r3d.createRightMatcher(left)
+    wls = r3d.createDisparityWLSFilter(left)
+    wls.setLambda(8000)
+    wls.setSigmaColor(1.5)
+    left._ctx = right._ctx = wls._ctx = ctx
+
+    def frame():
+        for src, dst, g in ((d_fl, d_rl, d_gl), (d_fr, d_rr, d_gr)):
+            ctx.call("r3d_remap_u8_dev", vp(src), W, H, W * 3, 3, vp(d_m1), vp(d_m2), W, H, 0, vp(dst), vp(g))
+        left.compute_device(d_gl, d_gr, W, H, W, d_dl)
+        right.compute_device(d_gr, d_gl, W, H, W, d_dr)
+        wls.filter_device(d_dl, d_dr, d_gl, 1, W, W, H, d_f)
+        ctx.call("r3d_normalize_minmax_s16_dev", vp(d_f), W * H, 0.0, 255.0, vp(d_n))
+    for _ in range(2):
+        frame()
+    ctx.sync()
+    e0, e1 = ctx.event(), ctx.event()
+    ctx.record(e0)
+    for _ in range(reps):
+        frame()
+    ctx.record(e1)
+    ctx.sync()
+    ms = ctx.elapsed_ms(e0, e1) / reps
+    for b in bufs:
+        ctx.free(b)
+    return {"metric": "depth2.py frame iterations/s @8MP d=128 (remap+grey x2, SGBM left+right, WLS filter, normalize)",
+            "value": round(1e3 / ms, 2), "unit": "frames/s", "ms_per_frame": round(ms, 4), "frames": reps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,7 +134,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gicp", action="store_true", help="skip the secondary metric (GICP iterations/s at 1M points)")
-    ap.add_argument("--no-pipelined", action="store_true", help="skip the informational three-maps-in-flight leg")
+    ap.add_argument("--extras", action="store_true",
+                    help="add two informational legs after the timed region: the same maps with three in flight "
+                         "(batch entry point) and one depth2.py frame iteration (remap, both matchers, WLS filter, "
+                         "normalize).  Off by default so that a rocprofv3 --stats summary of the default command "
+                         "averages every SGM kernel over un-overlapped C2 launches only, like the `roofline` object")
     ap.add_argument("--lanes", type=int, default=1,
                     help="maps in flight per GPU. 1 (default): strictly one map after the other, so that the per-kernel HIP-event "
                          "durations behind `roofline` are uncontended and agree with rocprofv3 --stats; 3: the K maps go through "
@@ -179,7 +236,7 @@ def main():
                    "sample": f"{n} full 3264x2448 D=128 maps, C restatement of OpenCV StereoSGBM 3WAY "
                              f"(oracle/sgbm3way.c, -O3 AVX2), host has {os.cpu_count()} cpus"}
         piped = None
-        if world == 1 and lanes == 1 and not args.no_pipelined:
+        if world == 1 and lanes == 1 and args.extras:
             # informational second leg (not `value`): the same maps through the batch entry point, three in flight on
             # the library's lanes, so the cost / hscan / vscan kernels of consecutive maps overlap
             ctx.set_profiling(False)
@@ -195,6 +252,10 @@ def main():
                      "ms_per_map": round(1e3 * (tp1 - tp0) / nb, 4),
                      "pipeline_frac": round(ALG_BYTES["map"] * nb / (tp1 - tp0) / HBM_PEAK, 4),
                      "entry_point": "r3d_sgbm_compute_batch_dev"}
+        frame_loop = None
+        if world == 1 and args.extras:
+            ctx.set_profiling(False)
+            frame_loop = bench_frame_loop(r3d, ctx, dL, dR)
         gicp = None
         if world == 1 and not args.no_gicp:
             gicp = bench_gicp(r3d, ctx, cpu=not args.no_cpu_baseline)
@@ -206,7 +267,7 @@ def main():
                                       "MODE_SGBM_3WAY (depth2.py params), one pair per GPU resident in HBM",
                           "parallelism": f"dp{world} (one view per GPU, no collective in the SGM step)",
                           "maps_in_flight_per_gpu": lanes},
-               "roofline": roofline, "cpu_baseline": cpu, "pipelined": piped, "secondary": gicp}
+               "roofline": roofline, "cpu_baseline": cpu, "pipelined": piped, "frame_loop": frame_loop, "secondary": gicp}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
