@@ -232,9 +232,31 @@ def main():
                 so.compute(L, R, p, nthreads=threads)
                 n += 1
             dt = time.perf_counter() - tc
+            model = "unknown"
+            try:
+                with open("/proc/cpuinfo") as f:
+                    model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), model)
+            except OSError:
+                pass
             cpu = {"value": round(n / dt, 3), "unit": "disparity-maps/s", "cores": threads, "kind": "port",
                    "sample": f"{n} full 3264x2448 D=128 maps, C restatement of OpenCV StereoSGBM 3WAY "
-                             f"(oracle/sgbm3way.c, -O3 AVX2), host has {os.cpu_count()} cpus"}
+                             f"(oracle/sgbm3way.c, -O3 AVX2), host has {os.cpu_count()} cpus ({model})"}
+            try:                                             # the real reference path, if this box ever has it
+                import cv2
+            except ImportError:
+                cv2 = None
+            if cv2 is not None:
+                cv2.setNumThreads(threads)
+                ref = cv2.StereoSGBM_create(numDisparities=D, mode=cv2.STEREO_SGBM_MODE_SGBM_3WAY, **C2_KW)
+                n = 0
+                tc = time.perf_counter()
+                while n < 3 or (time.perf_counter() - tc < 8.0 and n < 40):
+                    ref.compute(L, R)
+                    n += 1
+                dt = time.perf_counter() - tc
+                cpu = {"value": round(n / dt, 3), "unit": "disparity-maps/s", "cores": threads, "kind": "reference",
+                       "sample": f"{n} full 3264x2448 D=128 maps, cv2 {cv2.__version__} StereoSGBM MODE_SGBM_3WAY, "
+                                 f"host has {os.cpu_count()} cpus ({model})", "port": cpu}
         piped = None
         if world == 1 and lanes == 1 and args.extras:
             # informational second leg (not `value`): the same maps through the batch entry point, three in flight on
