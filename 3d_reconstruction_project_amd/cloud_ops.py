@@ -15,6 +15,9 @@ _lib.register({
     "r3d_neighbor_score": ([_vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_double, _vp], ctypes.c_int),
     "r3d_reproject_disparity": ([_vp, _vp, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _vp,
                                  ctypes.POINTER(ctypes.c_int64)], ctypes.c_int),
+    "r3d_disparity_to_cloud_dev": ([_vp, _vp, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_int32, ctypes.c_double, _vp,
+                                    ctypes.c_double, ctypes.c_double, ctypes.c_int32, ctypes.c_int64, _vp, _vp,
+                                    ctypes.POINTER(ctypes.c_int64)], ctypes.c_int),
     "r3d_knn_graph": ([_vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_double, _vp, _vp], ctypes.c_int),
     "r3d_orient_normals": ([_vp, _vp, ctypes.c_int64, ctypes.c_int32, _vp], ctypes.c_int),
     "r3d_transform_points": ([_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int32, _vp], ctypes.c_int),
@@ -79,6 +82,24 @@ def reproject_disparity(disp, Q, min_disparity=0, want_pixels=False, ctx=None):
              pix.ctypes.data_as(_vp) if want_pixels else None, ctypes.byref(m))
     out = out[:m.value].copy()
     return (out, pix[:m.value].copy()) if want_pixels else out
+
+
+def disparity_to_cloud_device(d_disp, width, height, Q, min_disparity=0, max_depth=None, pose=None, voxel=0.01,
+                              normal_radius=None, max_nn=30, capacity=None, ctx=None):
+    """Device-resident disparity -> cloud chain (r3d_disparity_to_cloud_dev): d_disp is the device pointer (int) of an
+    int16 [height,width] map as written by StereoSGBM.compute_device.  Returns (points [M,3], normals [M,3] or None)."""
+    ctx = ctx or _lib.default_context()
+    Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(4, 4)
+    P = None if pose is None else np.ascontiguousarray(pose, dtype=np.float64).reshape(4, 4)
+    cap = int(capacity) if capacity is not None else int(width) * int(height)
+    pts = np.empty((cap, 3))
+    nrm = np.empty((cap, 3)) if max_nn and max_nn > 0 else None
+    m = ctypes.c_int64()
+    ctx.call("r3d_disparity_to_cloud_dev", _vp(d_disp), int(width), int(height), _ptr(Q), int(min_disparity) * 16,
+             float(max_depth) if max_depth else -1.0, _ptr(P), float(voxel) if voxel else -1.0,
+             float(normal_radius) if normal_radius else -1.0, int(max_nn) if max_nn else 0, cap, _ptr(pts), _ptr(nrm),
+             ctypes.byref(m))
+    return pts[:m.value].copy(), (nrm[:m.value].copy() if nrm is not None else None)
 
 
 def knn_graph(points, k, radius=0.0, want_d2=True, ctx=None):

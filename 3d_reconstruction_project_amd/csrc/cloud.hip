@@ -705,6 +705,16 @@ __global__ void __launch_bounds__(256) k_disp_flags(const int16_t *__restrict__ 
     if (i < n) flags[i] = disp[i] >= min_valid ? 1 : 0;
 }
 struct Mat4 { double m[16]; };
+// same, and additionally |Z/W| <= max_depth (the value k_reproject will write, computed by the same expressions)
+__global__ void __launch_bounds__(256) k_disp_flags_depth(const int16_t *__restrict__ disp, int w, int64_t n, int min_valid, Mat4 Q,
+                                                         double max_depth, int *__restrict__ flags) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double x = (double)(i % w), y = (double)(i / w), d = (double)disp[i] / 16.0;
+    const double Z = Q.m[8] * x + Q.m[9] * y + Q.m[10] * d + Q.m[11];
+    const double W = Q.m[12] * x + Q.m[13] * y + Q.m[14] * d + Q.m[15];
+    flags[i] = (disp[i] >= min_valid && fabs(Z / W) <= max_depth) ? 1 : 0;
+}
 __global__ void __launch_bounds__(256) k_reproject(const int16_t *__restrict__ disp, const int *__restrict__ flags, const int *__restrict__ scan,
                                                    int w, int64_t n, Mat4 Q, double *__restrict__ xyz, int *__restrict__ pix) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -754,6 +764,11 @@ int cloud_bbox(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, doubl
     for (int a = 0; a < 3; a++) { mn[a] = 1e300; mx[a] = -1e300; }
     for (int b = 0; b < nb; b++)
         for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], h[(size_t)b * 6 + a]); mx[a] = std::max(mx[a], h[(size_t)b * 6 + 3 + a]); }
+    // a point at infinity (e.g. a zero disparity reprojected through Q) or a NaN has no cell: refuse instead of building a
+    // grid around it (fmin/fmax drop NaNs, so those show up as an untouched +-1e300 bound only if every value is NaN)
+    for (int a = 0; a < 3; a++)
+        if (!std::isfinite(mn[a]) || !std::isfinite(mx[a]) || mn[a] > mx[a] || std::fabs(mn[a]) > 1e290 || std::fabs(mx[a]) > 1e290)
+            return r3d_fail(ctx, R3D_E_BADARG, "cloud has non-finite coordinates (axis %d spans [%g, %g])", a, mn[a], mx[a]);
     return R3D_OK;
 }
 
@@ -970,6 +985,100 @@ int upload(r3d_ctx *ctx, DevArena &ar, const double *h, int64_t n3, double **d) 
 }  // namespace
 
 // ================================================================================================ C ABI
+// ---- device-pointer cores shared by the host-buffer entry points and the fused device-resident chain -------------
+
+// disparity (device) -> compacted xyz (device).  max_depth > 0 additionally drops points with |z| > max_depth.
+int reproject_core(r3d_ctx *ctx, DevArena &ar, const int16_t *d_d, int w, int h, const double *Q4x4, int min_valid_x16, double max_depth,
+                   bool want_pix, double **d_xyz_out, int **d_pix_out, int64_t *m_out) {
+    const int64_t n = (int64_t)w * h;
+    if (n > 0x7fffffff) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "reproject_disparity: image too large");
+    int *flags = (int *)ar.get((size_t)n * 4), *scan = (int *)ar.get((size_t)n * 4);
+    if (ar.rc) return ar.rc;
+    Mat4 Q;
+    memcpy(Q.m, Q4x4, sizeof Q.m);
+    const int nb = (int)((n + 255) / 256);
+    if (max_depth > 0) k_disp_flags_depth<<<nb, 256, 0, ctx->stream>>>(d_d, w, n, min_valid_x16, Q, max_depth, flags);
+    else k_disp_flags<<<nb, 256, 0, ctx->stream>>>(d_d, n, min_valid_x16, flags);
+    size_t tb = 0;
+    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flags, scan, (int)n, ctx->stream));
+    void *tmp = ar.get(tb);
+    if (ar.rc) return ar.rc;
+    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tb, flags, scan, (int)n, ctx->stream));
+    int ls = 0, lf = 0;
+    R3D_HIP(ctx, hipMemcpyAsync(&ls, scan + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipMemcpyAsync(&lf, flags + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t m = (int64_t)ls + lf;
+    *m_out = m;
+    *d_xyz_out = nullptr;
+    if (d_pix_out) *d_pix_out = nullptr;
+    if (m == 0) return R3D_OK;
+    double *d_xyz = (double *)ar.get((size_t)m * 24);
+    int *d_pix = want_pix ? (int *)ar.get((size_t)m * 4) : nullptr;
+    if (ar.rc) return ar.rc;
+    k_reproject<<<nb, 256, 0, ctx->stream>>>(d_d, flags, scan, w, n, Q, d_xyz, d_pix);
+    R3D_HIP(ctx, hipGetLastError());
+    *d_xyz_out = d_xyz;
+    if (d_pix_out) *d_pix_out = d_pix;
+    return R3D_OK;
+}
+
+// voxel grid of a device cloud: segments of equal legacy voxel index, in lexicographic index order
+struct VoxelSegs {
+    int *idx = nullptr, *starts = nullptr;
+    int64_t nseg = 0;
+};
+int voxel_segments(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, double voxel, VoxelSegs &V) {
+    double mn[3], mx[3];
+    int rc;
+    if ((rc = cloud_bbox(ctx, ar, d_p, n, mn, mx))) return rc;
+    double org[3];
+    int dims[3];
+    double total = 1;
+    for (int a = 0; a < 3; a++) {
+        org[a] = mn[a] - 0.5 * voxel;  // legacy: voxel_min_bound = min_bound - voxel_size * 0.5
+        dims[a] = (int)std::floor((mx[a] - org[a]) / voxel) + 2;
+        total *= dims[a];
+    }
+    if (total >= 1.8e19) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "voxel_downsample: voxel grid exceeds 2^64 cells");
+    unsigned long long *keys;
+    // key_order 1: exact legacy index floor((p - origin) / voxel), z fastest => output in lexicographic (kx,ky,kz) order
+    if ((rc = sort_by_cell(ctx, ar, d_p, n, org, voxel, dims, 1, &keys, &V.idx))) return rc;
+    int *flags = (int *)ar.get((size_t)n * 4), *scan = (int *)ar.get((size_t)n * 4);
+    V.starts = (int *)ar.get((size_t)n * 4);
+    if (ar.rc) return ar.rc;
+    const int nb = (int)((n + 255) / 256);
+    k_seg_flags<<<nb, 256, 0, ctx->stream>>>(keys, n, flags);
+    size_t tb = 0;
+    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flags, scan, (int)n, ctx->stream));
+    void *tmp = ar.get(tb);
+    if (ar.rc) return ar.rc;
+    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tb, flags, scan, (int)n, ctx->stream));
+    k_seg_starts<<<nb, 256, 0, ctx->stream>>>(flags, scan, n, V.starts);
+    int last_scan = 0, last_flag = 0;
+    R3D_HIP(ctx, hipMemcpyAsync(&last_scan, scan + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipMemcpyAsync(&last_flag, flags + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    V.nseg = (int64_t)last_scan + last_flag;
+    return R3D_OK;
+}
+
+// normals of a device cloud into a fresh device buffer
+int normals_core(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, double radius, int max_nn, const double *d_prev, double **d_n_out) {
+    Grid G;
+    const int k = (int)std::min<int64_t>(max_nn, n);
+    int rc;
+    if ((rc = grid_build(ctx, ar, d_p, n, radius, std::max(2.0, k / 5.0), G))) return rc;
+    double *d_n = (double *)ar.get((size_t)n * 24);
+    if (ar.rc) return ar.rc;
+    const size_t lds = (size_t)k * KNN_BLOCK * 12;
+    R3D_HIP(ctx, hipFuncSetAttribute((const void *)k_normals, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_normals<<<(unsigned)((n + KNN_BLOCK - 1) / KNN_BLOCK), KNN_BLOCK, lds, ctx->stream>>>(G.v, n, k, radius, d_prev, d_n, nullptr);
+    R3D_HIP(ctx, hipGetLastError());
+    *d_n_out = d_n;
+    return R3D_OK;
+}
+
 extern "C" {
 
 int r3d_voxel_downsample(r3d_ctx *ctx, const double *xyz, const double *colors, const double *normals, int64_t n, double voxel,
@@ -984,36 +1093,9 @@ int r3d_voxel_downsample(r3d_ctx *ctx, const double *xyz, const double *colors, 
     if ((rc = upload(ctx, ar, xyz, n * 3, &d_p))) return rc;
     if (colors && (rc = upload(ctx, ar, colors, n * 3, &d_c))) return rc;
     if (normals && (rc = upload(ctx, ar, normals, n * 3, &d_n))) return rc;
-    double mn[3], mx[3];
-    if ((rc = cloud_bbox(ctx, ar, d_p, n, mn, mx))) return rc;
-    double org[3];
-    int dims[3];
-    double total = 1;
-    for (int a = 0; a < 3; a++) {
-        org[a] = mn[a] - 0.5 * voxel;  // legacy: voxel_min_bound = min_bound - voxel_size * 0.5
-        dims[a] = (int)std::floor((mx[a] - org[a]) / voxel) + 2;
-        total *= dims[a];
-    }
-    if (total >= 1.8e19) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "voxel_downsample: voxel grid exceeds 2^64 cells");
-    unsigned long long *keys;
-    int *idx;
-    // key_order 1: exact legacy index floor((p - origin) / voxel), z fastest => output in lexicographic (kx,ky,kz) order
-    if ((rc = sort_by_cell(ctx, ar, d_p, n, org, voxel, dims, 1, &keys, &idx))) return rc;
-    int *flags = (int *)ar.get((size_t)n * 4), *scan = (int *)ar.get((size_t)n * 4), *starts = (int *)ar.get((size_t)n * 4);
-    if (ar.rc) return ar.rc;
-    const int nb = (int)((n + 255) / 256);
-    k_seg_flags<<<nb, 256, 0, ctx->stream>>>(keys, n, flags);
-    size_t tb = 0;
-    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flags, scan, (int)n, ctx->stream));
-    void *tmp = ar.get(tb);
-    if (ar.rc) return ar.rc;
-    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tb, flags, scan, (int)n, ctx->stream));
-    k_seg_starts<<<nb, 256, 0, ctx->stream>>>(flags, scan, n, starts);
-    int last_scan = 0, last_flag = 0;
-    R3D_HIP(ctx, hipMemcpyAsync(&last_scan, scan + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    R3D_HIP(ctx, hipMemcpyAsync(&last_flag, flags + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const int64_t nseg = (int64_t)last_scan + last_flag;
+    VoxelSegs V;
+    if ((rc = voxel_segments(ctx, ar, d_p, n, voxel, V))) return rc;
+    const int64_t nseg = V.nseg;
     double *d_out = (double *)ar.get((size_t)nseg * 24);
     if (ar.rc) return ar.rc;
     const int nbs = (int)((nseg + 255) / 256);
@@ -1021,7 +1103,7 @@ int r3d_voxel_downsample(r3d_ctx *ctx, const double *xyz, const double *colors, 
     double *outs[3] = {out_xyz, out_colors, out_normals};
     for (int a = 0; a < 3; a++) {
         if (!ins[a]) continue;
-        k_voxel_mean<<<nbs, 256, 0, ctx->stream>>>(ins[a], idx, starts, nseg, n, d_out);
+        k_voxel_mean<<<nbs, 256, 0, ctx->stream>>>(ins[a], V.idx, V.starts, nseg, n, d_out);
         R3D_HIP(ctx, hipGetLastError());
         R3D_HIP(ctx, hipMemcpyAsync(outs[a], d_out, (size_t)nseg * 24, hipMemcpyDeviceToHost, ctx->stream));
         R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1037,19 +1119,11 @@ int r3d_estimate_normals(r3d_ctx *ctx, const double *xyz, int64_t n, double radi
     if (max_nn > 128) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "estimate_normals: max_nn > 128 not supported");
     R3D_HIP(ctx, hipSetDevice(ctx->device));
     DevArena ar(ctx);
-    double *d_p, *d_prev = nullptr;
+    double *d_p, *d_prev = nullptr, *d_n;
     int rc;
     if ((rc = upload(ctx, ar, xyz, n * 3, &d_p))) return rc;
     if (prev_normals && (rc = upload(ctx, ar, prev_normals, n * 3, &d_prev))) return rc;
-    Grid G;
-    const int k = (int)std::min<int64_t>(max_nn, n);
-    if ((rc = grid_build(ctx, ar, d_p, n, radius, std::max(2.0, k / 5.0), G))) return rc;
-    double *d_n = (double *)ar.get((size_t)n * 24);
-    if (ar.rc) return ar.rc;
-    const size_t lds = (size_t)k * KNN_BLOCK * 12;
-    R3D_HIP(ctx, hipFuncSetAttribute((const void *)k_normals, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_normals<<<(unsigned)((n + KNN_BLOCK - 1) / KNN_BLOCK), KNN_BLOCK, lds, ctx->stream>>>(G.v, n, k, radius, d_prev, d_n, nullptr);
-    R3D_HIP(ctx, hipGetLastError());
+    if ((rc = normals_core(ctx, ar, d_p, n, radius, max_nn, d_prev, &d_n))) return rc;
     R3D_HIP(ctx, hipMemcpyAsync(normals, d_n, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->stream));
     R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return R3D_OK;
@@ -1084,35 +1158,63 @@ int r3d_reproject_disparity(r3d_ctx *ctx, const int16_t *disp, int32_t w, int32_
     if (!disp || !Q4x4 || !out_xyz || !out_n || w <= 0 || h <= 0) return r3d_fail(ctx, R3D_E_BADARG, "reproject_disparity: bad argument");
     R3D_HIP(ctx, hipSetDevice(ctx->device));
     DevArena ar(ctx);
-    const int64_t n = (int64_t)w * h;
-    if (n > 0x7fffffff) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "reproject_disparity: image too large");
-    int16_t *d_d = (int16_t *)ar.get((size_t)n * 2);
-    int *flags = (int *)ar.get((size_t)n * 4), *scan = (int *)ar.get((size_t)n * 4);
+    const size_t n = (size_t)w * h;
+    int16_t *d_d = (int16_t *)ar.get(n * 2);
     if (ar.rc) return ar.rc;
-    R3D_HIP(ctx, hipMemcpyAsync(d_d, disp, (size_t)n * 2, hipMemcpyHostToDevice, ctx->stream));
-    const int nb = (int)((n + 255) / 256);
-    k_disp_flags<<<nb, 256, 0, ctx->stream>>>(d_d, n, min_valid_x16, flags);
-    size_t tb = 0;
-    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flags, scan, (int)n, ctx->stream));
-    void *tmp = ar.get(tb);
-    if (ar.rc) return ar.rc;
-    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tb, flags, scan, (int)n, ctx->stream));
-    int ls = 0, lf = 0;
-    R3D_HIP(ctx, hipMemcpyAsync(&ls, scan + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    R3D_HIP(ctx, hipMemcpyAsync(&lf, flags + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const int64_t m = (int64_t)ls + lf;
+    R3D_HIP(ctx, hipMemcpyAsync(d_d, disp, n * 2, hipMemcpyHostToDevice, ctx->stream));
+    double *d_xyz;
+    int *d_pix;
+    int64_t m;
+    int rc;
+    if ((rc = reproject_core(ctx, ar, d_d, w, h, Q4x4, min_valid_x16, 0.0, out_pixel != nullptr, &d_xyz, &d_pix, &m))) return rc;
     *out_n = m;
     if (m == 0) return R3D_OK;
-    double *d_xyz = (double *)ar.get((size_t)m * 24);
-    int *d_pix = out_pixel ? (int *)ar.get((size_t)m * 4) : nullptr;
-    if (ar.rc) return ar.rc;
-    Mat4 Q;
-    memcpy(Q.m, Q4x4, sizeof Q.m);
-    k_reproject<<<nb, 256, 0, ctx->stream>>>(d_d, flags, scan, w, n, Q, d_xyz, d_pix);
-    R3D_HIP(ctx, hipGetLastError());
     R3D_HIP(ctx, hipMemcpyAsync(out_xyz, d_xyz, (size_t)m * 24, hipMemcpyDeviceToHost, ctx->stream));
     if (out_pixel) R3D_HIP(ctx, hipMemcpyAsync(out_pixel, d_pix, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return R3D_OK;
+}
+
+int r3d_disparity_to_cloud_dev(r3d_ctx *ctx, const int16_t *d_disp, int32_t w, int32_t h, const double *Q4x4, int32_t min_valid_x16,
+                               double max_depth, const double *pose4x4, double voxel, double normal_radius, int32_t max_nn,
+                               int64_t capacity, double *out_xyz, double *out_normals, int64_t *out_n) {
+    if (!ctx) return R3D_E_BADARG;
+    if (!d_disp || !Q4x4 || !out_xyz || !out_n || w <= 0 || h <= 0 || capacity < 0)
+        return r3d_fail(ctx, R3D_E_BADARG, "disparity_to_cloud: bad argument");
+    if (max_nn > 128) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "disparity_to_cloud: max_nn > 128 not supported");
+    if (max_nn > 0 && !out_normals) return r3d_fail(ctx, R3D_E_BADARG, "disparity_to_cloud: normals requested without an output array");
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    DevArena ar(ctx);
+    double *d_p;
+    int64_t m;
+    int rc;
+    // depth filter off: still drop points at infinity (W = 0, e.g. disparity 0), which no voxel grid can hold
+    if ((rc = reproject_core(ctx, ar, d_disp, w, h, Q4x4, min_valid_x16, max_depth > 0 ? max_depth : 1.0e300, false, &d_p, nullptr, &m))) return rc;
+    *out_n = 0;
+    if (m == 0) return R3D_OK;
+    if (pose4x4) {
+        double *d_t = (double *)ar.get((size_t)m * 24);
+        if (ar.rc) return ar.rc;
+        k_transform<<<(unsigned)((m + 255) / 256), 256, 0, ctx->stream>>>(d_p, m, to_rigid(pose4x4), 0, d_t);
+        R3D_HIP(ctx, hipGetLastError());
+        d_p = d_t;
+    }
+    if (voxel > 0) {
+        VoxelSegs V;
+        if ((rc = voxel_segments(ctx, ar, d_p, m, voxel, V))) return rc;
+        double *d_v = (double *)ar.get((size_t)V.nseg * 24);
+        if (ar.rc) return ar.rc;
+        k_voxel_mean<<<(unsigned)((V.nseg + 255) / 256), 256, 0, ctx->stream>>>(d_p, V.idx, V.starts, V.nseg, m, d_v);
+        R3D_HIP(ctx, hipGetLastError());
+        d_p = d_v;
+        m = V.nseg;
+    }
+    *out_n = m;
+    if (m > capacity) return r3d_fail(ctx, R3D_E_BADARG, "disparity_to_cloud: %lld points, output arrays hold %lld", (long long)m, (long long)capacity);
+    double *d_n = nullptr;
+    if (max_nn > 0 && (rc = normals_core(ctx, ar, d_p, m, normal_radius, max_nn, nullptr, &d_n))) return rc;
+    R3D_HIP(ctx, hipMemcpyAsync(out_xyz, d_p, (size_t)m * 24, hipMemcpyDeviceToHost, ctx->stream));
+    if (d_n) R3D_HIP(ctx, hipMemcpyAsync(out_normals, d_n, (size_t)m * 24, hipMemcpyDeviceToHost, ctx->stream));
     R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return R3D_OK;
 }

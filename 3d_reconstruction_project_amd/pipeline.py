@@ -48,12 +48,31 @@ def scaled_Q(Q, scale, unit=1.0):
     return Q
 
 
-def view_to_cloud(left, right, Q, matcher, voxel=0.01, normal_radius=None, max_nn=30, pose=None, max_depth=None):
-    """One stereo view -> down-sampled cloud with normals.  pose (4x4, optional) is applied to the cloud."""
+def view_to_cloud(left, right, Q, matcher, voxel=0.01, normal_radius=None, max_nn=30, pose=None, max_depth=None,
+                  device_resident=True):
+    """One stereo view -> down-sampled cloud with normals.  pose (4x4, optional) is applied to the cloud.
+    device_resident (default): the disparity map never leaves HBM; the matcher writes it with compute_device and
+    r3d_disparity_to_cloud_dev chains reprojection, depth filter, pose, voxel grid and normals on the device, so only the
+    two input images go up and the final cloud comes down.  False: the same stages through the host-buffer entry points
+    (identical results; kept for callers that want the intermediate arrays)."""
+    if device_resident:
+        ctx = matcher.context
+        L = np.ascontiguousarray(left, dtype=np.uint8)
+        R = np.ascontiguousarray(right, dtype=np.uint8)
+        H, W = L.shape
+        d_l, d_r, d_d = ctx.to_device(L), ctx.to_device(R), ctx.alloc(W * H * 2)
+        try:
+            matcher.compute_device(d_l, d_r, W, H, W, d_d)
+            pts, nrm = cloud_ops.disparity_to_cloud_device(d_d, W, H, Q, matcher.getMinDisparity(), max_depth, pose, voxel,
+                                                           normal_radius or 2 * voxel, max_nn, ctx=ctx)
+        finally:
+            for p in (d_l, d_r, d_d):
+                ctx.free(p)
+        return PointCloud(pts, normals=nrm) if len(pts) else PointCloud()
     disp = matcher.compute(left, right)
     pts = cloud_ops.reproject_disparity(disp, Q, matcher.getMinDisparity())
-    if max_depth is not None and len(pts):
-        pts = pts[np.abs(pts[:, 2]) <= max_depth]
+    if len(pts):                                       # zero disparities reproject to infinity (W = 0): never part of a cloud
+        pts = pts[np.abs(pts[:, 2]) <= (max_depth if max_depth is not None else 1.0e300)]
     if len(pts) == 0:
         return PointCloud()
     if pose is not None:

@@ -134,6 +134,17 @@ int r3d_neighbor_score(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, do
 int r3d_reproject_disparity(r3d_ctx *ctx, const int16_t *disp, int32_t w, int32_t h, const double *Q4x4, int32_t min_valid_x16,
                             double *out_xyz, int32_t *out_pixel, int64_t *out_n);
 
+/* Device-resident join of the two halves ("SGM -> disparity -> cloud -> voxel -> normals, all
+ * device-resident"): takes the DEVICE disparity map r3d_sgbm_compute_dev wrote and chains reprojectImageTo3D semantics
+ * -> |z| <= max_depth filter (max_depth <= 0: only points at infinity, W = 0, are dropped) -> rigid pose (pose4x4 may be NULL) -> voxel_down_sample(voxel)
+ * (voxel <= 0: off) -> estimate_normals(KDTreeSearchParamHybrid(normal_radius, max_nn)) (max_nn <= 0: off; radius <= 0: kNN)
+ * without leaving HBM; only the final cloud is copied to the host arrays (room for `capacity` triplets each; out_normals
+ * may be NULL when max_nn <= 0).  *out_n = points produced; R3D_E_BADARG if they exceed capacity.  Same kernels and
+ * arithmetic as the separate host-buffer entry points, so the results are identical to chaining those. */
+int r3d_disparity_to_cloud_dev(r3d_ctx *ctx, const int16_t *d_disp, int32_t w, int32_t h, const double *Q4x4, int32_t min_valid_x16,
+                               double max_depth, const double *pose4x4, double voxel, double normal_radius, int32_t max_nn,
+                               int64_t capacity, double *out_xyz, double *out_normals, int64_t *out_n);
+
 /* k-nearest-neighbour graph (indices in the caller's numbering, nearest first, the point itself first; missing
  * entries -1 / 1e300).  radius <= 0: unbounded.  Feeds orient_normals_consistent_tangent_plane(k)
  * (normal_estimation.py:21), whose spanning-tree propagation is sequential host work.  d2 may be NULL. */

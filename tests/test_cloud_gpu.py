@@ -286,3 +286,14 @@ def test_lds_tiled_search_kernel_matches_default():
         assert a[3] == b[3] and int(a[3]) > 50000                                     # correspondences
         Ta, Tb = (np.frombuffer(bytes.fromhex(x[2])).reshape(4, 4) for x in (a, b))
         assert np.abs(Ta - Tb).max() < 1e-12 and abs(float(a[4]) - float(b[4])) < 1e-12
+
+
+def test_non_finite_coordinates_are_refused(r3d):
+    """A zero disparity reprojects to infinity; a grid around such a point cannot be built, so the cloud entry points raise
+    instead of looping or indexing with garbage."""
+    pts = np.random.default_rng(0).random((1000, 3))
+    pts[17, 1] = np.inf
+    with pytest.raises(r3d.R3DError, match="non-finite"):
+        r3d.cloud_ops.voxel_down_sample(pts, 0.1)
+    with pytest.raises(r3d.R3DError, match="non-finite"):
+        r3d.cloud_ops.estimate_normals(pts, 0.2, 10)

@@ -63,3 +63,44 @@ def test_view_to_cloud_and_single_rank_multi_view(r3d, synth):
     R_err = Ts[1][:3, :3] @ poses[1][:3, :3].T
     ang = np.degrees(np.arccos(np.clip((np.trace(R_err) - 1) / 2, -1, 1)))
     assert ang < 0.2 and np.abs(Ts[1][:3, 3] - poses[1][:3, 3]).max() < 2e-3
+
+
+def test_device_resident_view_chain_equals_host_chain_and_oracle(r3d, synth):
+    """r3d_disparity_to_cloud_dev (SGM map stays in HBM -> reprojection -> depth filter -> pose -> voxel grid -> normals) must
+    give exactly what chaining the host-buffer entry points gives, and that equals the oracle chain."""
+    from oracle import sgbm_oracle as so
+    W, H, D = 512, 300, 64
+    Q = r3d.pipeline.scaled_Q(np.load(os.path.join(GOLDEN, "jetson_stereo_8MP_stereo.npz"))["Q"], W / 960.0, unit=1e-3)
+    m = r3d.reference_matcher(numDisparities=D, blockSize=5)
+    L, R, _ = synth.stereo_pair(W, H, D, seed=77)
+    pose = synth.rigid((0.2, 1, 0.1), 3.0, (0.01, -0.02, 0.005))
+    kw = dict(voxel=0.004, pose=pose, max_depth=0.6, max_nn=20)
+    a = r3d.pipeline.view_to_cloud(L, R, Q, m, device_resident=True, **kw)
+    b = r3d.pipeline.view_to_cloud(L, R, Q, m, device_resident=False, **kw)
+    assert len(a) > 1000
+    np.testing.assert_array_equal(a.points, b.points)
+    np.testing.assert_array_equal(a.normals, b.normals)
+    # oracle chain on the oracle's disparity map
+    kwm = dict(minDisparity=0, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1, uniquenessRatio=15, speckleWindowSize=0,
+               speckleRange=2, preFilterCap=63)
+    disp = so.compute(L, R, so.make_params(numDisparities=D, **kwm), nthreads=4)
+    ys, xs = np.nonzero(disp >= 0)
+    v = np.stack([xs, ys, disp[ys, xs] / 16.0, np.ones(len(xs))], 0).astype(np.float64)
+    X = Q @ v
+    pts = (X[:3] / X[3]).T
+    pts = pts[np.abs(pts[:, 2]) <= 0.6]
+    pts = co.transform_points(pose, pts)
+    pts = co.voxel_down_sample(pts, 0.004)
+    order = lambda p: p[np.lexsort(p.T[::-1])]                                           # noqa: E731
+    np.testing.assert_allclose(order(a.points), order(pts), atol=1e-9)
+    # options off: raw reprojection only
+    ctx = m.context
+    d_l, d_r, d_d = ctx.to_device(L), ctx.to_device(R), ctx.alloc(W * H * 2)
+    m.compute_device(d_l, d_r, W, H, W, d_d)
+    raw, nrm = r3d.cloud_ops.disparity_to_cloud_device(d_d, W, H, Q, 0, None, None, 0, None, 0, ctx=ctx)
+    assert nrm is None and len(raw) == int((disp >= 0).sum())
+    np.testing.assert_array_equal(raw, r3d.cloud_ops.reproject_disparity(disp, Q, 0))
+    with pytest.raises(r3d.R3DError):
+        r3d.cloud_ops.disparity_to_cloud_device(d_d, W, H, Q, 0, None, None, 0, None, 0, capacity=10, ctx=ctx)
+    for p in (d_l, d_r, d_d):
+        ctx.free(p)
