@@ -28,6 +28,17 @@ _lib.register({
 P2P, P2PLANE, GICP = 0, 1, 2
 
 
+class AlignParams(ctypes.Structure):
+    _fields_ = [("icp", _lib.IcpParams), ("voxel_size", ctypes.c_double), ("normal_radius", ctypes.c_double),
+                ("normal_max_nn", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+_lib.register({
+    "r3d_align_point_clouds": ([_vp, ctypes.POINTER(AlignParams), _vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _vp, _vp, _vp,
+                                _vp, ctypes.POINTER(ctypes.c_int64), _vp, ctypes.POINTER(_lib.IcpStats)], ctypes.c_int),
+})
+
+
 def _c(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 3)
 
@@ -156,3 +167,31 @@ def registration(source, target, max_correspondence_distance, init=None, mode=P2
     return dict(T=T, fitness=st.fitness, inlier_rmse=st.inlier_rmse, iterations=st.iterations,
                 converged=bool(st.converged), correspondences=st.correspondences, setup_ms=st.setup_ms,
                 loop_ms=st.loop_ms)
+
+
+def align_point_clouds(source, target, threshold=0.02, voxel_size=0.01, max_iteration=100, mode=P2P, normal_radius=None,
+                       normal_max_nn=30, source_colors=None, init=None, relative_fitness=1e-6, relative_rmse=1e-6,
+                       gicp_epsilon=1e-3, ctx=None):
+    """The body of PointCloudAlignment.align_point_clouds (pointcloud_alignment.py:6-43) as one device-resident call
+    (r3d_align_point_clouds): voxel_down_sample both -> normals on both -> registration -> transform the source.
+    Returns dict(points, colors, normals, T, fitness, ...): the down-sampled, transformed source."""
+    ctx = ctx or _lib.default_context()
+    s, t, sc = _c(source), _c(target), _c(source_colors)
+    T0 = None if init is None else np.ascontiguousarray(init, dtype=np.float64).reshape(4, 4)
+    prm = AlignParams(_lib.IcpParams(int(mode), int(max_iteration), float(threshold), float(relative_fitness),
+                                     float(relative_rmse), float(gicp_epsilon)),
+                      float(voxel_size) if voxel_size else -1.0,
+                      float(normal_radius) if normal_radius else (2.0 * voxel_size if voxel_size else -1.0),
+                      int(normal_max_nn) if normal_max_nn else 0, 0)
+    op = np.empty((len(s), 3))
+    oc = np.empty((len(s), 3)) if sc is not None else None
+    on = np.empty((len(s), 3)) if prm.normal_max_nn > 0 else None
+    T = np.empty((4, 4))
+    m = ctypes.c_int64()
+    st = _lib.IcpStats()
+    ctx.call("r3d_align_point_clouds", ctypes.byref(prm), _ptr(s), _ptr(sc), len(s), _ptr(t), len(t), _ptr(T0), _ptr(op),
+             _ptr(oc), _ptr(on), ctypes.byref(m), _ptr(T), ctypes.byref(st))
+    m = m.value
+    return dict(points=op[:m].copy(), colors=None if oc is None else oc[:m].copy(), normals=None if on is None else on[:m].copy(),
+                T=T, fitness=st.fitness, inlier_rmse=st.inlier_rmse, iterations=st.iterations, converged=bool(st.converged),
+                correspondences=st.correspondences, setup_ms=st.setup_ms, loop_ms=st.loop_ms)

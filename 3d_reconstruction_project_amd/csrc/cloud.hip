@@ -1079,6 +1079,111 @@ int normals_core(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, doubl
     return R3D_OK;
 }
 
+// ICP / point-to-plane / GICP loop on clouds that are already in device memory (d_sn / d_tn may be null where the mode
+// allows it); everything below r3d_icp's argument checks and uploads
+static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double *d_s, int64_t ns, double *d_sn, double *d_t, int64_t nt,
+                    double *d_tn, const double *init4x4, double *T4x4, r3d_icp_stats *stats,
+                    std::chrono::steady_clock::time_point t_begin) {
+    int rc;
+    Grid G;
+    if ((rc = grid_build(ctx, ar, d_t, nt, p->max_correspondence_distance, 3.0, G))) return rc;
+    double *d_tns = nullptr;
+    if (d_tn) {
+        d_tns = (double *)ar.get((size_t)nt * 24);
+        if (ar.rc) return ar.rc;
+        k_gather3<<<(unsigned)((nt + 255) / 256), 256, 0, ctx->stream>>>(d_tn, G.v.idx, nt, d_tns);
+    }
+    // spatially sort the source once (Morton order of the target-grid cell of its initial pose) so that neighbouring threads
+    // walk the same cells; sums are order-dependent only at the 1e-16 level and stay deterministic
+    double T[16];
+    if (init4x4) memcpy(T, init4x4, sizeof T);
+    else for (int i = 0; i < 16; i++) T[i] = (i % 5 == 0);
+    {
+        double *d_s0 = (double *)ar.get((size_t)ns * 24);
+        if (ar.rc) return ar.rc;
+        k_transform<<<(unsigned)((ns + 255) / 256), 256, 0, ctx->stream>>>(d_s, ns, to_rigid(T), 0, d_s0);
+        int dims[3] = {G.v.nx, G.v.ny, G.v.nz};
+        unsigned long long *sk;
+        int *sidx;
+        if ((rc = sort_by_cell(ctx, ar, d_s0, ns, G.mn, G.v.cell, dims, 2, &sk, &sidx))) return rc;
+        double *d_ss = (double *)ar.get((size_t)ns * 24);
+        if (ar.rc) return ar.rc;
+        k_gather3<<<(unsigned)((ns + 255) / 256), 256, 0, ctx->stream>>>(d_s, sidx, ns, d_ss);
+        d_s = d_ss;
+        if (d_sn) {
+            double *d_sns = (double *)ar.get((size_t)ns * 24);
+            if (ar.rc) return ar.rc;
+            k_gather3<<<(unsigned)((ns + 255) / 256), 256, 0, ctx->stream>>>(d_sn, sidx, ns, d_sns);
+            d_sn = d_sns;
+        }
+    }
+    // default: per-lane search straight from global memory (L1/L2-cached gathers); R3D_ICP_IMPL=tiled selects the LDS-tiled
+    // kernel, kept for A/B: measured 0.31 vs 0.26 ms per GICP iteration at 1M points (staging + barriers cost more than
+    // the gathers they replace once the source is Morton-ordered)
+    const char *impl_env = getenv("R3D_ICP_IMPL");
+    const bool tiled_impl = impl_env && strcmp(impl_env, "tiled") == 0;
+    const int nblocks = tiled_impl ? (int)std::min<int64_t>((ns + 63) / 64, 8192) : (int)std::min<int64_t>((ns + ICP_BLOCK - 1) / ICP_BLOCK, 2048);
+    double *d_part = (double *)ar.get((size_t)nblocks * ICP_SLOTS * 8), *d_sum = (double *)ar.get(ICP_SLOTS * 8);
+    if (ar.rc) return ar.rc;
+    double sums[ICP_SLOTS];
+    auto eval = [&](const double Tm[16]) -> int {
+        Rigid R = to_rigid(Tm);
+        const double eps = p->gicp_epsilon > 0 ? p->gicp_epsilon : 1e-3;
+        const double md = p->max_correspondence_distance;
+        if (tiled_impl) {
+            switch (p->mode) {
+                case MODE_P2P: k_icp_eval_t<MODE_P2P><<<nblocks, 64, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, md, eps, d_part, nullptr); break;
+                case MODE_P2PLANE: k_icp_eval_t<MODE_P2PLANE><<<nblocks, 64, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, md, eps, d_part, nullptr); break;
+                default: k_icp_eval_t<MODE_GICP><<<nblocks, 64, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, md, eps, d_part, nullptr); break;
+            }
+        } else {
+            switch (p->mode) {
+                case MODE_P2P: k_icp_eval<MODE_P2P><<<nblocks, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, md, eps, d_part, nullptr); break;
+                case MODE_P2PLANE: k_icp_eval<MODE_P2PLANE><<<nblocks, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, md, eps, d_part, nullptr); break;
+                default: k_icp_eval<MODE_GICP><<<nblocks, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, md, eps, d_part, nullptr); break;
+            }
+        }
+        k_icp_final<<<ICP_SLOTS, 64, 0, ctx->stream>>>(d_part, nblocks, d_sum);
+        R3D_HIP(ctx, hipGetLastError());
+        R3D_HIP(ctx, hipMemcpyAsync(sums, d_sum, sizeof sums, hipMemcpyDeviceToHost, ctx->stream));
+        R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return R3D_OK;
+    };
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t_loop = std::chrono::steady_clock::now();
+    if ((rc = eval(T))) return rc;
+    double fit = sums[0] / (double)ns, rmse = sums[0] > 0 ? sqrt(sums[1] / sums[0]) : 0.0;
+    int it = 0, converged = 0;
+    const int max_it = p->max_iteration;
+    for (it = 1; it <= max_it; it++) {
+        double U[16];
+        for (int i = 0; i < 16; i++) U[i] = (i % 5 == 0);
+        if (sums[0] > 0) {
+            if (p->mode == MODE_P2P) umeyama_from_sums(sums, U);
+            else solve6_to_matrix(sums, U);
+        }
+        mat4_mul(U, T, T);
+        const double pf = fit, pr = rmse;
+        if ((rc = eval(T))) return rc;
+        fit = sums[0] / (double)ns;
+        rmse = sums[0] > 0 ? sqrt(sums[1] / sums[0]) : 0.0;
+        if (fabs(pf - fit) < p->relative_fitness && fabs(pr - rmse) < p->relative_rmse) { converged = 1; break; }
+    }
+    if (it > max_it) it = max_it;
+    memcpy(T4x4, T, sizeof T);
+    if (stats) {
+        stats->iterations = it;
+        stats->converged = converged;
+        stats->correspondences = (int64_t)sums[0];
+        stats->fitness = fit;
+        stats->inlier_rmse = rmse;
+        const auto t_end = std::chrono::steady_clock::now();
+        stats->setup_ms = std::chrono::duration<double, std::milli>(t_loop - t_begin).count();
+        stats->loop_ms = std::chrono::duration<double, std::milli>(t_end - t_loop).count();
+    }
+    return R3D_OK;
+}
+
 extern "C" {
 
 int r3d_voxel_downsample(r3d_ctx *ctx, const double *xyz, const double *colors, const double *normals, int64_t n, double voxel,
@@ -1219,6 +1324,69 @@ int r3d_disparity_to_cloud_dev(r3d_ctx *ctx, const int16_t *d_disp, int32_t w, i
     return R3D_OK;
 }
 
+int r3d_align_point_clouds(r3d_ctx *ctx, const r3d_align_params *p, const double *src, const double *src_colors, int64_t ns,
+                           const double *tgt, int64_t nt, const double *init4x4, double *out_xyz, double *out_colors,
+                           double *out_normals, int64_t *out_n, double *T4x4, r3d_icp_stats *stats) {
+    if (!ctx) return R3D_E_BADARG;
+    if (!p || !src || !tgt || !out_xyz || !out_n || !T4x4 || ns <= 0 || nt <= 0) return r3d_fail(ctx, R3D_E_BADARG, "align: bad argument");
+    if (src_colors && !out_colors) return r3d_fail(ctx, R3D_E_BADARG, "align: colours given without an output array");
+    const r3d_icp_params *ip = &p->icp;
+    if (ip->mode < 0 || ip->mode > 2) return r3d_fail(ctx, R3D_E_BADARG, "align: mode must be 0 (P2P), 1 (P2PLANE) or 2 (GICP)");
+    if (!(ip->max_correspondence_distance > 0)) return r3d_fail(ctx, R3D_E_BADARG, "align: max_correspondence_distance must be > 0");
+    if (p->normal_max_nn > 128) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "align: normal_max_nn > 128 not supported");
+    if (ip->mode != MODE_P2P && p->normal_max_nn <= 0) return r3d_fail(ctx, R3D_E_BADARG, "align: this mode needs normals (normal_max_nn > 0)");
+    if (p->normal_max_nn > 0 && !out_normals) return r3d_fail(ctx, R3D_E_BADARG, "align: normals requested without an output array");
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    const auto t_begin = std::chrono::steady_clock::now();
+    DevArena ar(ctx);
+    int rc;
+    double *d_s, *d_t, *d_c = nullptr;
+    if ((rc = upload(ctx, ar, src, ns * 3, &d_s))) return rc;
+    if ((rc = upload(ctx, ar, tgt, nt * 3, &d_t))) return rc;
+    if (src_colors && (rc = upload(ctx, ar, src_colors, ns * 3, &d_c))) return rc;
+    int64_t ms = ns, mt = nt;
+    if (p->voxel_size > 0) {  // pointcloud_alignment.py:22-23
+        VoxelSegs V;
+        if ((rc = voxel_segments(ctx, ar, d_s, ns, p->voxel_size, V))) return rc;
+        double *d_sv = (double *)ar.get((size_t)V.nseg * 24), *d_cv = d_c ? (double *)ar.get((size_t)V.nseg * 24) : nullptr;
+        if (ar.rc) return ar.rc;
+        k_voxel_mean<<<(unsigned)((V.nseg + 255) / 256), 256, 0, ctx->stream>>>(d_s, V.idx, V.starts, V.nseg, ns, d_sv);
+        if (d_c) k_voxel_mean<<<(unsigned)((V.nseg + 255) / 256), 256, 0, ctx->stream>>>(d_c, V.idx, V.starts, V.nseg, ns, d_cv);
+        R3D_HIP(ctx, hipGetLastError());
+        d_s = d_sv;
+        d_c = d_cv;
+        ms = V.nseg;
+        VoxelSegs Vt;
+        if ((rc = voxel_segments(ctx, ar, d_t, nt, p->voxel_size, Vt))) return rc;
+        double *d_tv = (double *)ar.get((size_t)Vt.nseg * 24);
+        if (ar.rc) return ar.rc;
+        k_voxel_mean<<<(unsigned)((Vt.nseg + 255) / 256), 256, 0, ctx->stream>>>(d_t, Vt.idx, Vt.starts, Vt.nseg, nt, d_tv);
+        R3D_HIP(ctx, hipGetLastError());
+        d_t = d_tv;
+        mt = Vt.nseg;
+    }
+    double *d_sn = nullptr, *d_tn = nullptr;
+    if (p->normal_max_nn > 0) {  // pointcloud_alignment.py:27-28
+        if ((rc = normals_core(ctx, ar, d_s, ms, p->normal_radius, p->normal_max_nn, nullptr, &d_sn))) return rc;
+        if ((rc = normals_core(ctx, ar, d_t, mt, p->normal_radius, p->normal_max_nn, nullptr, &d_tn))) return rc;
+    }
+    double T[16];
+    if ((rc = icp_core(ctx, ar, ip, d_s, ms, d_sn, d_t, mt, d_tn, init4x4, T, stats, t_begin))) return rc;  // :35-39
+    memcpy(T4x4, T, sizeof T);
+    double *d_o = (double *)ar.get((size_t)ms * 24), *d_on = d_sn ? (double *)ar.get((size_t)ms * 24) : nullptr;
+    if (ar.rc) return ar.rc;
+    const unsigned nb = (unsigned)((ms + 255) / 256);
+    k_transform<<<nb, 256, 0, ctx->stream>>>(d_s, ms, to_rigid(T), 0, d_o);  // :42 source.transform
+    if (d_sn) k_transform<<<nb, 256, 0, ctx->stream>>>(d_sn, ms, to_rigid(T), 1, d_on);
+    R3D_HIP(ctx, hipGetLastError());
+    R3D_HIP(ctx, hipMemcpyAsync(out_xyz, d_o, (size_t)ms * 24, hipMemcpyDeviceToHost, ctx->stream));
+    if (d_sn) R3D_HIP(ctx, hipMemcpyAsync(out_normals, d_on, (size_t)ms * 24, hipMemcpyDeviceToHost, ctx->stream));
+    if (d_c) R3D_HIP(ctx, hipMemcpyAsync(out_colors, d_c, (size_t)ms * 24, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out_n = ms;
+    return R3D_OK;
+}
+
 int r3d_knn_graph(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, double radius, int32_t *nbr, double *d2) {
     if (!ctx) return R3D_E_BADARG;
     if (!xyz || !nbr || n <= 0 || k < 1) return r3d_fail(ctx, R3D_E_BADARG, "knn_graph: bad argument");
@@ -1349,104 +1517,8 @@ int r3d_icp(r3d_ctx *ctx, const r3d_icp_params *p, const double *src, int64_t ns
     if ((rc = upload(ctx, ar, tgt, nt * 3, &d_t))) return rc;
     if ((rc = upload(ctx, ar, src, ns * 3, &d_s))) return rc;
     if (src_normals && (rc = upload(ctx, ar, src_normals, ns * 3, &d_sn))) return rc;
-    Grid G;
-    if ((rc = grid_build(ctx, ar, d_t, nt, p->max_correspondence_distance, 3.0, G))) return rc;
-    double *d_tns = nullptr;
-    if (tgt_normals) {
-        if ((rc = upload(ctx, ar, tgt_normals, nt * 3, &d_tn))) return rc;
-        d_tns = (double *)ar.get((size_t)nt * 24);
-        if (ar.rc) return ar.rc;
-        k_gather3<<<(unsigned)((nt + 255) / 256), 256, 0, ctx->stream>>>(d_tn, G.v.idx, nt, d_tns);
-    }
-    // spatially sort the source once (Morton order of the target-grid cell of its initial pose) so that neighbouring threads
-    // walk the same cells; sums are order-dependent only at the 1e-16 level and stay deterministic
-    double T[16];
-    if (init4x4) memcpy(T, init4x4, sizeof T);
-    else for (int i = 0; i < 16; i++) T[i] = (i % 5 == 0);
-    {
-        double *d_s0 = (double *)ar.get((size_t)ns * 24);
-        if (ar.rc) return ar.rc;
-        k_transform<<<(unsigned)((ns + 255) / 256), 256, 0, ctx->stream>>>(d_s, ns, to_rigid(T), 0, d_s0);
-        int dims[3] = {G.v.nx, G.v.ny, G.v.nz};
-        unsigned long long *sk;
-        int *sidx;
-        if ((rc = sort_by_cell(ctx, ar, d_s0, ns, G.mn, G.v.cell, dims, 2, &sk, &sidx))) return rc;
-        double *d_ss = (double *)ar.get((size_t)ns * 24);
-        if (ar.rc) return ar.rc;
-        k_gather3<<<(unsigned)((ns + 255) / 256), 256, 0, ctx->stream>>>(d_s, sidx, ns, d_ss);
-        d_s = d_ss;
-        if (d_sn) {
-            double *d_sns = (double *)ar.get((size_t)ns * 24);
-            if (ar.rc) return ar.rc;
-            k_gather3<<<(unsigned)((ns + 255) / 256), 256, 0, ctx->stream>>>(d_sn, sidx, ns, d_sns);
-            d_sn = d_sns;
-        }
-    }
-    // default: per-lane search straight from global memory (L1/L2-cached gathers); R3D_ICP_IMPL=tiled selects the LDS-tiled
-    // kernel, kept for A/B: measured 0.31 vs 0.26 ms per GICP iteration at 1M points (staging + barriers cost more than
-    // the gathers they replace once the source is Morton-ordered)
-    const char *impl_env = getenv("R3D_ICP_IMPL");
-    const bool tiled_impl = impl_env && strcmp(impl_env, "tiled") == 0;
-    const int nblocks = tiled_impl ? (int)std::min<int64_t>((ns + 63) / 64, 8192) : (int)std::min<int64_t>((ns + ICP_BLOCK - 1) / ICP_BLOCK, 2048);
-    double *d_part = (double *)ar.get((size_t)nblocks * ICP_SLOTS * 8), *d_sum = (double *)ar.get(ICP_SLOTS * 8);
-    if (ar.rc) return ar.rc;
-    double sums[ICP_SLOTS];
-    auto eval = [&](const double Tm[16]) -> int {
-        Rigid R = to_rigid(Tm);
-        const double eps = p->gicp_epsilon > 0 ? p->gicp_epsilon : 1e-3;
-        const double md = p->max_correspondence_distance;
-        if (tiled_impl) {
-            switch (p->mode) {
-                case MODE_P2P: k_icp_eval_t<MODE_P2P><<<nblocks, 64, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, md, eps, d_part, nullptr); break;
-                case MODE_P2PLANE: k_icp_eval_t<MODE_P2PLANE><<<nblocks, 64, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, md, eps, d_part, nullptr); break;
-                default: k_icp_eval_t<MODE_GICP><<<nblocks, 64, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, md, eps, d_part, nullptr); break;
-            }
-        } else {
-            switch (p->mode) {
-                case MODE_P2P: k_icp_eval<MODE_P2P><<<nblocks, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, md, eps, d_part, nullptr); break;
-                case MODE_P2PLANE: k_icp_eval<MODE_P2PLANE><<<nblocks, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, md, eps, d_part, nullptr); break;
-                default: k_icp_eval<MODE_GICP><<<nblocks, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, md, eps, d_part, nullptr); break;
-            }
-        }
-        k_icp_final<<<ICP_SLOTS, 64, 0, ctx->stream>>>(d_part, nblocks, d_sum);
-        R3D_HIP(ctx, hipGetLastError());
-        R3D_HIP(ctx, hipMemcpyAsync(sums, d_sum, sizeof sums, hipMemcpyDeviceToHost, ctx->stream));
-        R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        return R3D_OK;
-    };
-    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const auto t_loop = std::chrono::steady_clock::now();
-    if ((rc = eval(T))) return rc;
-    double fit = sums[0] / (double)ns, rmse = sums[0] > 0 ? sqrt(sums[1] / sums[0]) : 0.0;
-    int it = 0, converged = 0;
-    const int max_it = p->max_iteration;
-    for (it = 1; it <= max_it; it++) {
-        double U[16];
-        for (int i = 0; i < 16; i++) U[i] = (i % 5 == 0);
-        if (sums[0] > 0) {
-            if (p->mode == MODE_P2P) umeyama_from_sums(sums, U);
-            else solve6_to_matrix(sums, U);
-        }
-        mat4_mul(U, T, T);
-        const double pf = fit, pr = rmse;
-        if ((rc = eval(T))) return rc;
-        fit = sums[0] / (double)ns;
-        rmse = sums[0] > 0 ? sqrt(sums[1] / sums[0]) : 0.0;
-        if (fabs(pf - fit) < p->relative_fitness && fabs(pr - rmse) < p->relative_rmse) { converged = 1; break; }
-    }
-    if (it > max_it) it = max_it;
-    memcpy(T4x4, T, sizeof T);
-    if (stats) {
-        stats->iterations = it;
-        stats->converged = converged;
-        stats->correspondences = (int64_t)sums[0];
-        stats->fitness = fit;
-        stats->inlier_rmse = rmse;
-        const auto t_end = std::chrono::steady_clock::now();
-        stats->setup_ms = std::chrono::duration<double, std::milli>(t_loop - t_begin).count();
-        stats->loop_ms = std::chrono::duration<double, std::milli>(t_end - t_loop).count();
-    }
-    return R3D_OK;
+    if (tgt_normals && (rc = upload(ctx, ar, tgt_normals, nt * 3, &d_tn))) return rc;
+    return icp_core(ctx, ar, p, d_s, ns, d_sn, d_t, nt, d_tn, init4x4, T4x4, stats, t_begin);
 }
 
 }  // extern "C"

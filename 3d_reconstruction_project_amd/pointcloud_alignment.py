@@ -17,22 +17,16 @@ class PointCloudAlignment:
         """pointcloud_alignment.py:6-43: voxel_down_sample both clouds, estimate_normals(Hybrid(2*voxel, 30)) on both,
         registration_icp(PointToPoint, criteria(1e-6, 1e-6, max_iter)) from identity, transform the source."""
         sp, sc, _ = as_arrays(source)
-        tp, tc, _ = as_arrays(target)
-        if self.verbose:
+        tp, _, _ = as_arrays(target)
+        if self.verbose:                                    # the reference's three progress lines, kept verbatim
             print("Downsampling point clouds using voxel size:", voxel_size)
-        sp, sc, _ = cloud_ops.voxel_down_sample(sp, voxel_size, sc)
-        tp, tc, _ = cloud_ops.voxel_down_sample(tp, voxel_size, tc)
-        if self.verbose:
-            print("Estimating normals on CPU...")          # the reference's own (inaccurate) message, kept verbatim
-        sn = cloud_ops.estimate_normals(sp, voxel_size * 2, 30)
-        tn = cloud_ops.estimate_normals(tp, voxel_size * 2, 30)
-        if self.verbose:
+            print("Estimating normals on CPU...")
             print("Performing ICP alignment using CUDA...")
         mode = {"point_to_point": cloud_ops.P2P, "point_to_plane": cloud_ops.P2PLANE, "gicp": cloud_ops.GICP}[self.method]
-        res = cloud_ops.registration(sp, tp, threshold, np.eye(4), mode, max_iter, 1e-6, 1e-6, sn, tn)
+        # one device-resident call: both clouds go up once, the down-sampled transformed source comes back
+        res = cloud_ops.align_point_clouds(sp, tp, threshold, voxel_size, max_iter, mode, voxel_size * 2, 30, source_colors=sc)
         self.last_result = res
-        T = res["T"]
-        return like(source, cloud_ops.transform_points(sp, T), sc, cloud_ops.transform_points(sn, T, rotate_only=True))
+        return like(source, res["points"], res["colors"], res["normals"])
 
     # north_star alias
     align = align_point_clouds

@@ -185,6 +185,24 @@ typedef struct {
 int r3d_icp(r3d_ctx *ctx, const r3d_icp_params *p, const double *src, int64_t ns, const double *src_normals, const double *tgt,
             int64_t nt, const double *tgt_normals, const double *init4x4, double *T4x4, r3d_icp_stats *stats);
 
+/* replaces: the whole body of PointCloudAlignment.align_point_clouds (pointcloud_alignment.py:6-43; caller main.py:48) in ONE
+ * call, device-resident between the stages: voxel_down_sample(voxel_size) of both clouds (:22-23) ->
+ * estimate_normals(KDTreeSearchParamHybrid(normal_radius, normal_max_nn)) on both (:27-28) -> registration (:35-39) ->
+ * source.transform(T) (:42).  Returns what the reference returns: the DOWN-SAMPLED, transformed source (points, colours
+ * averaged per voxel, rotated normals).  out arrays need room for ns triplets; out_colors only with src_colors; out_normals
+ * only when normal_max_nn > 0.  voxel_size <= 0 skips the down-sampling; stats->setup_ms then covers everything before the
+ * ICP loop.  Same kernels as the separate entry points: identical results to chaining those. */
+typedef struct r3d_align_params {
+    r3d_icp_params icp;
+    double voxel_size;
+    double normal_radius;
+    int32_t normal_max_nn;
+    int32_t reserved;
+} r3d_align_params;
+int r3d_align_point_clouds(r3d_ctx *ctx, const r3d_align_params *p, const double *src, const double *src_colors, int64_t ns,
+                           const double *tgt, int64_t nt, const double *init4x4, double *out_xyz, double *out_colors,
+                           double *out_normals, int64_t *out_n, double *T4x4, r3d_icp_stats *stats);
+
 /* ---- per-frame stages either side of the matcher in Calib_depth/depth*.py --------------
  * OpenCV is a dependency of the reference that is absent here, and the reference records no output of these calls:
  * parity of this group is UNPINNED (restated from OpenCV 4.x's published algorithms; see oracle/prepost_oracle.py). */

@@ -297,3 +297,32 @@ def test_non_finite_coordinates_are_refused(r3d):
         r3d.cloud_ops.voxel_down_sample(pts, 0.1)
     with pytest.raises(r3d.R3DError, match="non-finite"):
         r3d.cloud_ops.estimate_normals(pts, 0.2, 10)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_fused_align_call_equals_chained_entry_points(r3d, mode):
+    """r3d_align_point_clouds (one device-resident call) == voxel_down_sample x2 -> estimate_normals x2 -> registration ->
+    transform through the separate host-buffer entry points: same kernels, so bit-identical outputs."""
+    ops = r3d.cloud_ops
+    src, tgt = _frame("output84", 10), _frame("output84", 8)
+    rng = np.random.default_rng(0)
+    col = rng.random(src.shape)
+    got = ops.align_point_clouds(src, tgt, 0.02, 0.01, 40, mode, 0.02, 30, source_colors=col)
+    sp, sc, _ = ops.voxel_down_sample(src, 0.01, col)
+    tp, _, _ = ops.voxel_down_sample(tgt, 0.01)
+    sn, tn = ops.estimate_normals(sp, 0.02, 30), ops.estimate_normals(tp, 0.02, 30)
+    res = ops.registration(sp, tp, 0.02, np.eye(4), mode, 40, 1e-6, 1e-6, sn, tn)
+    np.testing.assert_array_equal(got["T"], res["T"])
+    assert got["iterations"] == res["iterations"] and got["correspondences"] == res["correspondences"]
+    np.testing.assert_array_equal(got["points"], ops.transform_points(sp, res["T"]))
+    np.testing.assert_array_equal(got["normals"], ops.transform_points(sn, res["T"], rotate_only=True))
+    np.testing.assert_array_equal(got["colors"], sc)
+    # no down-sampling, no normals: plain point-to-point on the raw clouds
+    if mode == 0:
+        raw = ops.align_point_clouds(sp, tp, 0.02, None, 10, 0, None, 0)
+        ref = ops.registration(sp, tp, 0.02, np.eye(4), 0, 10)
+        np.testing.assert_array_equal(raw["T"], ref["T"])
+        assert raw["normals"] is None and raw["colors"] is None and len(raw["points"]) == len(sp)
+    else:
+        with pytest.raises(r3d.R3DError):
+            ops.align_point_clouds(sp, tp, 0.02, None, 10, mode, None, 0)             # this mode needs normals
