@@ -279,6 +279,7 @@ int r3d_filter_speckles(r3d_ctx *ctx, int16_t *img, int32_t w, int32_t h, int32_
 int r3d_sgbm_debug_fetch(r3d_ctx *ctx, int16_t *cost, int16_t *hsum, int16_t *raw) {
     if (!ctx) return R3D_E_BADARG;
     if (ctx->last_w == 0) return r3d_fail(ctx, R3D_E_BADARG, "debug_fetch: no sgbm call yet");
+    if (ctx->last_w1 <= 0) return r3d_fail(ctx, R3D_E_BADARG, "debug_fetch: the last call had an empty matching range (all-invalid map), no volumes exist");
     R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const size_t vol = (size_t)ctx->last_h * ctx->last_w1 * ctx->last_dp * 2;
     if (cost) R3D_HIP(ctx, hipMemcpy(cost, ctx->ws[0].cost.p, vol, hipMemcpyDeviceToHost));

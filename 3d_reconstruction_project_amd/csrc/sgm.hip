@@ -265,6 +265,10 @@ __device__ __forceinline__ void bt_interval(int vm, int v, int vp, bool has_m, b
 // halo; a thread keeps the three rows of its column in registers and rolls them), the gradient / intensity pair of 258
 // positions is computed from LDS, and each thread forms its pixel's two intervals from its neighbours' pairs.  All global
 // loads use clamped coordinates (no branch around a load).
+__global__ void __launch_bounds__(256) k_fill_s16(int16_t *__restrict__ p, size_t n, int16_t v) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+
 #define PF_ROWS 8
 __global__ void __launch_bounds__(256) k_prefilter(const uint8_t *__restrict__ L, const uint8_t *__restrict__ R, int ld,
                                                    int W, int H, int ft, uint2 *__restrict__ recL, uint2 *__restrict__ recR) {
@@ -1560,7 +1564,7 @@ int derive_geom(r3d_ctx *ctx, const r3d_sgbm_params *p, int w, int h, SgmGeom &g
     g.minX1 = maxD > 0 ? maxD : 0;
     g.maxX1 = w + (g.minD < 0 ? g.minD : 0);
     g.W1 = g.maxX1 - g.minX1;
-    if (g.W1 <= 0) return r3d_fail(ctx, R3D_E_BADARG, "sgbm: image width %d too small for disparity range [%d, %d)", w, g.minD, maxD);
+    // W1 <= 0 (the disparity range leaves no column to match) is not an error: the caller fills the map with the invalid marker
     g.SW2 = g.SH2 = p->blockSize / 2;
     g.P1 = p->P1 > 0 ? p->P1 : 2;
     g.P2 = p->P2 > 0 ? p->P2 : 5;
@@ -1715,6 +1719,13 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
     if (!d_left || !d_right || !d_disp) return r3d_fail(ctx, R3D_E_BADARG, "sgbm: null image pointer");
     if (stride < w) return r3d_fail(ctx, R3D_E_BADARG, "sgbm: stride %d < width %d", stride, w);
     R3D_HIP(ctx, hipSetDevice(ctx->device));
+    if (g.W1 <= 0) {  // minX1 >= maxX1: like the original, an all-invalid map, no error
+        const size_t np = (size_t)w * h;
+        k_fill_s16<<<(unsigned)std::min<size_t>((np + 255) / 256, 4096), 256, 0, st>>>(d_disp, np, (int16_t)((g.minD - 1) * 16));
+        R3D_HIP(ctx, hipGetLastError());
+        ctx->last_w = w; ctx->last_h = h; ctx->last_w1 = 0; ctx->last_dp = 0;
+        return R3D_OK;
+    }
     const int NPW = g.NP * 64;
     const size_t npix = (size_t)w * h;
     const size_t rowBytes = (size_t)g.W1 * NPW * 4;

@@ -357,6 +357,15 @@ int sgbm_oracle_compute(const uint8_t *L, const uint8_t *R, int W, int H, int ld
                         const sgbm_oracle_params *p, int16_t *disp, int16_t *raw_or_null, int nthreads) {
     geom_t g;
     int rc = derive(p, W, H, &g);
+    if (rc == -2) {
+        /* minX1 >= maxX1: the disparity range leaves no column to match; the original fills the map with the invalid
+         * marker and returns [recalled: "if( minX1 >= maxX1 ) { disp1 = Scalar::all(INVALID_DISP_SCALED); return; }"] */
+        const int16_t inv = (int16_t)((p->minDisparity - 1) * DISP_SCALE);
+        for (size_t i = 0; i < (size_t)W * H; i++) disp[i] = inv;
+        if (raw_or_null)
+            for (size_t i = 0; i < (size_t)W * H; i++) raw_or_null[i] = inv;
+        return 0;
+    }
     if (rc) return rc;
     uint8_t tabmem[2304];
     for (int k = 0; k < 2304; k++) tabmem[k] = (uint8_t)(IMIN(IMAX(k - 1024, -g.ftzero), g.ftzero) + g.ftzero);

@@ -116,6 +116,18 @@ def test_errors_are_loud(r3d):
         r3d.StereoSGBM_create(numDisparities=16, mode=2).compute(L.astype(np.float32), L)
 
 
+def test_disparity_range_wider_than_the_image_gives_all_invalid_map(r3d):
+    """minX1 >= maxX1: the original fills the map with the invalid marker and returns; no exception (a user raising
+    numDisparities with the 'w' key of depth1.py:256-260 on a narrow stream must not crash the viewer)."""
+    L = np.random.default_rng(0).integers(0, 256, (12, 157), dtype=np.uint8)
+    kw = dict(C2_KW, minDisparity=16, blockSize=11)
+    got = _gpu(r3d, 144, kw).compute(L, L)
+    assert got.shape == L.shape and (got == 15 * 16).all()
+    np.testing.assert_array_equal(got, _oracle(L, L, 144, kw))
+    got = _gpu(r3d, 256, C2_KW).compute(L, L)
+    assert (got == -16).all()
+
+
 def test_full_size_8mp_bit_exact_and_properties(r3d, synth):
     """BASELINE config C2 (3264x2448, D=128, depth2.py parameters): the C oracle needs about a second for this size on
     the GPU box's host cores, so the full map is compared bit for bit; plus determinism, the invalid left band, the

@@ -94,3 +94,9 @@ def test_bad_params_rejected():
     L = np.zeros((8, 40), np.uint8)
     with pytest.raises(RuntimeError):
         so.compute(L, L, so.make_params(numDisparities=24, blockSize=5))
+
+
+def test_oracle_empty_matching_range_is_an_all_invalid_map():
+    L = np.random.default_rng(0).integers(0, 256, (9, 100), dtype=np.uint8)
+    d, raw = so.compute(L, L, so.make_params(numDisparities=112, blockSize=5, P1=600, P2=2400, preFilterCap=63), return_raw=True)
+    assert (d == -16).all() and (raw == -16).all()
