@@ -142,22 +142,41 @@ __device__ __forceinline__ void sgm_step_g(int (&P)[NPL], int &minp, const int (
     const int mp2 = as_i((s16x2){m16, m16});      // splat: folded into op_sel by the compiler
     const int up = grp_shr1<LPC>(P[NPL - 1], PADPK, first);
     const int dn = grp_shl1<LPC>(P[0], PADPK, last);
-    int Q[NPL];
+    // Stage by stage across all NPL registers ("breadth first"): on gfx950 a packed (VOP3P) result needs one wait state
+    // before a dependent VALU read, and the compiler fills it with s_nop instead of independent work when the source is
+    // written register by register; in this order every dependent pair is NPL instructions apart.
+    int Q[NPL], t1[NPL], t3[NPL], cm[NPL];
 #pragma unroll
     for (int j = 0; j < NPL; j++) {
         const int below = j == 0 ? up : P[j - 1];
         const int above = j == NPL - 1 ? dn : P[j + 1];
         const int A = __builtin_amdgcn_alignbit(P[j], below, 16);
         const int B = __builtin_amdgcn_alignbit(above, P[j], 16);
-        const int nb = pk_add_sat(pk_min(A, B), P1pk);
-        const int cm = pk_sub(C[j], mp2);                       // independent of the min chain
-        const int m = pk_min(pk_min(P[j], mp2), nb);
-        const int q = pk_add(cm, m);
+        t1[j] = pk_min(A, B);
+    }
+#pragma unroll
+    for (int j = 0; j < NPL; j++) cm[j] = pk_sub(C[j], mp2);  // independent of the min chain
+#pragma unroll
+    for (int j = 0; j < NPL; j++) t3[j] = pk_min(P[j], mp2);
+#pragma unroll
+    for (int j = 0; j < NPL; j++) t1[j] = pk_add_sat(t1[j], P1pk);
+#pragma unroll
+    for (int j = 0; j < NPL; j++) t3[j] = pk_min(t3[j], t1[j]);
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        const int q = pk_add(cm[j], t3[j]);
         Q[j] = (!PADDED || lane_valid) ? q : PADPK;
     }
-    int m = Q[0];
+    // balanced min tree (a linear chain would pay the wait state at every step)
+    int mt[NPL];
 #pragma unroll
-    for (int j = 1; j < NPL; j++) m = pk_min(m, Q[j]);
+    for (int j = 0; j < NPL; j++) mt[j] = Q[j];
+#pragma unroll
+    for (int w = NPL / 2; w >= 1; w /= 2) {
+#pragma unroll
+        for (int j = 0; j < w; j++) mt[j] = pk_min(mt[j], mt[j + w]);
+    }
+    const int m = mt[0];
 #pragma unroll
     for (int j = 0; j < NPL; j++) P[j] = Q[j];
     minp = grp_allmin<LPC>(min(lo16(m), hi16(m)));
@@ -261,14 +280,20 @@ __device__ __forceinline__ void bt_interval(int vm, int v, int vp, bool has_m, b
     lo = min(min(l, r), v);
     hi = max(max(l, r), v);
 }
-// One workgroup per 256-pixel column segment and band of PF_ROWS rows: every source row is read once (260 columns incl.
-// halo; a thread keeps the three rows of its column in registers and rolls them), the gradient / intensity pair of 258
-// positions is computed from LDS, and each thread forms its pixel's two intervals from its neighbours' pairs.  All global
-// loads use clamped coordinates (no branch around a load).
+
+// This file is compiled twice (csrc/build.sh): once as is, and once with -DR3D_TU_VSCAN and the ILP-oriented machine
+// scheduler, which then contributes only k_vscan2 and its launcher (the other kernels lose more to the larger register
+// footprint of that scheduler than they gain).  Everything up to here is shared by both translation units.
+#ifndef R3D_TU_VSCAN
+
 __global__ void __launch_bounds__(256) k_fill_s16(int16_t *__restrict__ p, size_t n, int16_t v) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
 }
 
+// One workgroup per 256-pixel column segment and band of PF_ROWS rows: every source row is read once (260 columns incl.
+// halo; a thread keeps the three rows of its column in registers and rolls them), the gradient / intensity pair of 258
+// positions is computed from LDS, and each thread forms its pixel's two intervals from its neighbours' pairs.  All global
+// loads use clamped coordinates (no branch around a load).
 #define PF_ROWS 8
 __global__ void __launch_bounds__(256) k_prefilter(const uint8_t *__restrict__ L, const uint8_t *__restrict__ R, int ld,
                                                    int W, int H, int ft, uint2 *__restrict__ recL, uint2 *__restrict__ recR) {
@@ -434,7 +459,6 @@ __global__ void __launch_bounds__(COST_NW * 64) k_cost(const uint2 *__restrict__
 //            (c) vertical sums go to an LDS tile; one barrier; (d) each lane adds the 2*SH2+1 neighbouring columns
 //                (ds_read_b128) and streams C to HBM, 2 KB contiguous per wave.
 // Borders: columns clamp in cost coordinates, rows clamp to [clampTop, h-1] (replication, as the original).
-constexpr int COST2_NWAVE = 8;
 
 // VCH (v3): the vertical path L_top is aggregated right here, on the freshly summed block cost that is still in
 // registers: one workgroup column-tile per STRIPE marches from the stripe's first warm-up row to its last row, and
@@ -1135,6 +1159,8 @@ __global__ void __launch_bounds__(64) k_hscan3(const int *__restrict__ cvol, con
     }
 }
 
+#endif  // !R3D_TU_VSCAN
+
 // ---------------------------------------------------------------------------------------------------------
 // k_vscan2: vertical path + winner-take-all with 16 disparities per lane (NPL = 8): LPC = DP/16 lanes per column,
 // CPW = 64/LPC adjacent columns per wave, each column an independent chain inside its lane group.  Everything after
@@ -1146,7 +1172,7 @@ __global__ void __launch_bounds__(64) k_vscan2(const int *__restrict__ cvol, con
                                                const int *__restrict__ hvol, SgmGeom g, float inv_a, int16_t *__restrict__ raw,
                                                int16_t *__restrict__ mins) {
     constexpr int CPW = 64 / LPC, DPW = NPL * LPC;  // columns per wave, words per column
-    static_assert(NPL == 4 || NPL == 8, "one or two 16-byte loads per lane");
+    static_assert(NPL == 4 || NPL == 8 || NPL == 16, "one, two or four 16-byte loads per lane");
     const int lane = threadIdx.x, k = lane % LPC, grp = lane / LPC, n = blockIdx.y;
     const int xc = blockIdx.x * CPW + grp;
     const bool col_ok = xc < g.W1;
@@ -1167,14 +1193,18 @@ __global__ void __launch_bounds__(64) k_vscan2(const int *__restrict__ cvol, con
         const int yy = min(y, src_end - 1);
         const int *cr = ((n > 0 && yy < src_start + g.SH2) ? cspec + ((size_t)(n - 1) * g.SH2 + (yy - src_start)) * rowWords
                                                              : cvol + (size_t)yy * rowWords) + off;
-        const int4 c0 = *(const int4 *)cr;
-        cb[0] = c0.x; cb[1] = c0.y; cb[2] = c0.z; cb[3] = c0.w;
-        if constexpr (NPL == 8) { const int4 c1 = *(const int4 *)(cr + 4); cb[4] = c1.x; cb[5] = c1.y; cb[6] = c1.z; cb[7] = c1.w; }
+#pragma unroll
+        for (int q = 0; q < NPL / 4; q++) {
+            const int4 c0 = *(const int4 *)(cr + 4 * q);
+            cb[4 * q] = c0.x; cb[4 * q + 1] = c0.y; cb[4 * q + 2] = c0.z; cb[4 * q + 3] = c0.w;
+        }
         if (yy >= out_start) {
             const int *hr = hvol + (size_t)yy * rowWords + off;
-            const int4 h0 = *(const int4 *)hr;
-            hb[0] = h0.x; hb[1] = h0.y; hb[2] = h0.z; hb[3] = h0.w;
-            if constexpr (NPL == 8) { const int4 h1 = *(const int4 *)(hr + 4); hb[4] = h1.x; hb[5] = h1.y; hb[6] = h1.z; hb[7] = h1.w; }
+#pragma unroll
+            for (int q = 0; q < NPL / 4; q++) {
+                const int4 h0 = *(const int4 *)(hr + 4 * q);
+                hb[4 * q] = h0.x; hb[4 * q + 1] = h0.y; hb[4 * q + 2] = h0.z; hb[4 * q + 3] = h0.w;
+            }
         }
     };
     auto process = [&](int y, int (&cb)[NPL], int (&hb)[NPL]) {
@@ -1199,7 +1229,14 @@ __global__ void __launch_bounds__(64) k_vscan2(const int *__restrict__ cvol, con
         auto fetch_s = [&](int d) -> int {
             const int j = (d >> 1) % NPL;
             int v;
-            if constexpr (NPL == 8) {
+            if constexpr (NPL == 16) {
+                const bool b0 = j & 1, b1 = j & 2, b2 = j & 4;
+                const int t0 = b0 ? S[1] : S[0], t1 = b0 ? S[3] : S[2], t2 = b0 ? S[5] : S[4], t3 = b0 ? S[7] : S[6];
+                const int t4 = b0 ? S[9] : S[8], t5 = b0 ? S[11] : S[10], t6 = b0 ? S[13] : S[12], t7 = b0 ? S[15] : S[14];
+                const int u0 = b1 ? t1 : t0, u1 = b1 ? t3 : t2, u2 = b1 ? t5 : t4, u3 = b1 ? t7 : t6;
+                const int w0 = b2 ? u1 : u0, w1 = b2 ? u3 : u2;
+                v = (j & 8) ? w1 : w0;
+            } else if constexpr (NPL == 8) {
                 const int t0 = (j & 1) ? S[1] : S[0], t1 = (j & 1) ? S[3] : S[2], t2 = (j & 1) ? S[5] : S[4], t3 = (j & 1) ? S[7] : S[6];
                 const int u0 = (j & 2) ? t1 : t0, u1 = (j & 2) ? t3 : t2;
                 v = (j & 4) ? u1 : u0;
@@ -1266,6 +1303,8 @@ __global__ void __launch_bounds__(64) k_vscan2(const int *__restrict__ cvol, con
         if (y + 3 < src_end) process(y + 3, c3, h3);
     }
 }
+
+#ifndef R3D_TU_VSCAN
 
 // ---------------------------------------------------------------------------------------------------------
 // k_lrcheck: per row: rebuild OpenCV's disp2 / disp2cost scatter (lowest cost wins, among equal costs the
@@ -1648,7 +1687,32 @@ int launch_cost2(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st,
     return g.NP == 1 ? launch_cost2_l<8, false>(ctx, ws, g, st) : launch_cost2_l<16, false>(ctx, ws, g, st);
 }
 
+#endif  // !R3D_TU_VSCAN
+
 }  // namespace
+
+#ifdef R3D_TU_VSCAN
+
+// launcher of k_vscan2 (this translation unit's only export).  geom: the SgmGeom of the call (its type lives in each unit's
+// anonymous namespace, hence the untyped pointer).  Variants: 16 columns per wave (NPL = 16, LPC = 4: 784 waves at C2, no
+// SIMD carries two; needs whole 32-disparity lanes) is the default where it applies, 8 columns (NPL = 8, LPC = 8) otherwise;
+// R3D_VSCAN_COLS = 4 | 8 | 16 forces one for A/B runs.
+int r3d_sgm_launch_vscan2(hipStream_t st, const void *geom, float inv_a, const int *cost, const int *cspec, const int *hsum,
+                          int16_t *raw, int16_t *mins) {
+    const SgmGeom &g = *(const SgmGeom *)geom;
+    static const int force = [] { const char *e = getenv("R3D_VSCAN_COLS"); return e ? atoi(e) : 0; }();
+    if (g.NP == 1) {
+        const bool ok16 = g.D % 32 == 0;
+        if ((force == 16 || force == 0) && ok16) k_vscan2<16, 4><<<dim3((g.W1 + 15) / 16, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins);
+        else if (force == 4) k_vscan2<4, 16><<<dim3((g.W1 + 3) / 4, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins);
+        else k_vscan2<8, 8><<<dim3((g.W1 + 7) / 8, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins);
+    } else {
+        k_vscan2<8, 16><<<dim3((g.W1 + 3) / 4, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins);
+    }
+    return (int)hipGetLastError();
+}
+
+#else  // !R3D_TU_VSCAN
 
 int r3d_streambench_run(r3d_ctx *ctx, int mode, int rows, size_t row_bytes, int write, int delay, int reps, float *ms) {
     R3D_HIP(ctx, hipSetDevice(ctx->device));
@@ -1839,10 +1903,9 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
             // D <= 128: 8 registers x 8 lanes per column = 8 columns per wave (1568 waves).  R3D_VSCAN_COLS=4 selects
             // 4 registers x 16 lanes (3136 finer-grained waves): measured 1.15 ms against 0.89 ms, the extra
             // cross-lane stages cost more than the better SIMD balance returns.
-            static const bool cols4 = [] { const char *e = getenv("R3D_VSCAN_COLS"); return e && !strcmp(e, "4"); }();
-            if (g.NP == 1 && cols4) k_vscan2<4, 16><<<dim3((g.W1 + 3) / 4, 4), 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, inv_a, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
-            else if (g.NP == 1) k_vscan2<8, 8><<<dim3((g.W1 + 7) / 8, 4), 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, inv_a, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
-            else k_vscan2<8, 16><<<dim3((g.W1 + 3) / 4, 4), 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, inv_a, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
+            if (int e = r3d_sgm_launch_vscan2(st, &g, inv_a, (const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p,
+                                              (int16_t *)ws.raw.p, (int16_t *)ws.mins.p))
+                return r3d_fail(ctx, R3D_E_HIP, "k_vscan2 launch failed: %s", hipGetErrorString((hipError_t)e));
         } else if (g.NP == 1) k_vscan<1, CPW><<<grid, 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
         else k_vscan<2, CPW><<<grid, 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
         R3D_HIP(ctx, hipGetLastError());
@@ -1861,3 +1924,5 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
     r3d_prof_end(ctx, ws, st);
     return R3D_OK;
 }
+
+#endif  // R3D_TU_VSCAN
