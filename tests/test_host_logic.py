@@ -76,3 +76,23 @@ def test_fuse_loop_skips_empty_frames_without_touching_the_gpu(r3d):
     first = r3d.PointCloud(np.random.default_rng(0).random((10, 3)), colors=np.ones((10, 3)))
     model = r3d.pipeline.fuse([None, r3d.PointCloud(), first, None])
     assert len(model) == 10 and model.has_colors() and not model.has_normals()
+
+
+def test_ply_triangle_mesh_round_trip(r3d, tmp_path):
+    """mesh_saving.py:15 writes the reconstructed mesh with write_triangle_mesh: vertices + `list uchar uint vertex_indices`."""
+    rng = np.random.default_rng(0)
+    pts = rng.normal(size=(50, 3))
+    nrm = rng.normal(size=(50, 3))
+    col = rng.random((50, 3))
+    faces = rng.integers(0, 50, (80, 3))
+    f = tmp_path / "mesh.ply"
+    r3d.io_formats.write_ply(str(f), pts, nrm, col, faces=faces)
+    head = f.read_bytes().split(b"end_header")[0].decode()
+    assert "element face 80" in head and "property list uchar uint vertex_indices" in head
+    back = r3d.io_formats.read_ply(str(f))
+    np.testing.assert_array_equal(back["points"], pts)
+    np.testing.assert_array_equal(back["normals"], nrm)
+    np.testing.assert_array_equal(back["faces"], faces)
+    np.testing.assert_array_equal(back["colors"], np.floor(col * 255 + 0.5).astype(np.uint8))
+    with pytest.raises(ValueError):
+        r3d.io_formats.write_ply(str(f), pts, faces=[[0, 1, 50]])
