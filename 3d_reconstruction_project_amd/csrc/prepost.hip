@@ -195,21 +195,16 @@ __global__ __launch_bounds__(64) void k_wls_dd(const int16_t *__restrict__ disp,
         const int16_t *row = disp + (size_t)reflect101(yy, H) * W + x0;
         int a = 0;
         long long a2 = 0;
-        if (inner) {
+        auto taps = [&](auto index) {
+            if constexpr (RT > 0) {
 #pragma unroll
-            for (int dx = -radius; dx <= radius; dx++) {
-                const int v = row[xc + dx];
-                a += v;
-                a2 += (long long)(v * v);
+                for (int dx = -RT; dx <= RT; dx++) { const int v = row[index(dx)]; a += v; a2 += (long long)(v * v); }
+            } else {
+                for (int dx = -radius; dx <= radius; dx++) { const int v = row[index(dx)]; a += v; a2 += (long long)(v * v); }
             }
-        } else {
-#pragma unroll
-            for (int dx = -radius; dx <= radius; dx++) {
-                const int v = row[reflect101(xc + dx, rw)];
-                a += v;
-                a2 += (long long)(v * v);
-            }
-        }
+        };
+        if (inner) taps([&](int dx) { return xc + dx; });
+        else taps([&](int dx) { return reflect101(xc + dx, rw); });
         s = a;
         s2 = a2;
     };
