@@ -26,6 +26,8 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 struct SgmGeom {
     int W, H, minD, D, NP, minX1, maxX1, W1, SW2, SH2, P1, P2, uniq, d12, ftzero, stripe_sz, overlap, invalid;
+    int DP;  // disparity slots per cost-volume column: the smallest of 32 / 64 / 128 / 256 that holds D (v2 kernels; v1 and v3
+             // only know 128 / 256 = NP * 128)
 };
 
 constexpr int PADPK = 0x7fff7fff;  // SHRT_MAX in both halves: the d=-1 / d=D padding of every path buffer
@@ -1599,6 +1601,7 @@ int derive_geom(r3d_ctx *ctx, const r3d_sgbm_params *p, int w, int h, SgmGeom &g
     g.W = w; g.H = h;
     g.minD = p->minDisparity; g.D = p->numDisparities;
     g.NP = g.D <= 128 ? 1 : 2;
+    g.DP = g.D <= 32 ? 32 : g.D <= 64 ? 64 : g.D <= 128 ? 128 : 256;
     const int maxD = g.minD + g.D;
     g.minX1 = maxD > 0 ? maxD : 0;
     g.maxX1 = w + (g.minD < 0 ? g.minD : 0);
@@ -1684,7 +1687,12 @@ int launch_cost2_l(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t s
 }
 int launch_cost2(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st, bool vch) {
     if (vch) return g.NP == 1 ? launch_cost2_l<8, true>(ctx, ws, g, st) : launch_cost2_l<16, true>(ctx, ws, g, st);
-    return g.NP == 1 ? launch_cost2_l<8, false>(ctx, ws, g, st) : launch_cost2_l<16, false>(ctx, ws, g, st);
+    switch (g.DP) {  // LPC = DP / 16 lanes per column
+        case 32: return launch_cost2_l<2, false>(ctx, ws, g, st);
+        case 64: return launch_cost2_l<4, false>(ctx, ws, g, st);
+        case 128: return launch_cost2_l<8, false>(ctx, ws, g, st);
+        default: return launch_cost2_l<16, false>(ctx, ws, g, st);
+    }
 }
 
 #endif  // !R3D_TU_VSCAN
@@ -1701,7 +1709,11 @@ int r3d_sgm_launch_vscan2(hipStream_t st, const void *geom, float inv_a, const i
                           int16_t *raw, int16_t *mins) {
     const SgmGeom &g = *(const SgmGeom *)geom;
     static const int force = [] { const char *e = getenv("R3D_VSCAN_COLS"); return e ? atoi(e) : 0; }();
-    if (g.NP == 1) {
+    if (g.DP == 32) {
+        k_vscan2<4, 4><<<dim3((g.W1 + 15) / 16, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins);
+    } else if (g.DP == 64) {
+        k_vscan2<8, 4><<<dim3((g.W1 + 15) / 16, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins);
+    } else if (g.DP == 128) {
         const bool ok16 = g.D % 32 == 0;
         if ((force == 16 || force == 0) && ok16) k_vscan2<16, 4><<<dim3((g.W1 + 15) / 16, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins);
         else if (force == 4) k_vscan2<4, 16><<<dim3((g.W1 + 3) / 4, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins);
@@ -1790,7 +1802,12 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
         ctx->last_w = w; ctx->last_h = h; ctx->last_w1 = 0; ctx->last_dp = 0;
         return R3D_OK;
     }
-    const int NPW = g.NP * 64;
+    // R3D_SGM_IMPL (read below as well): the v1 and v3 kernel generations only know 128 / 256 slots per column
+    {
+        const char *e = getenv("R3D_SGM_IMPL");
+        if (e && (!strcmp(e, "v1") || !strcmp(e, "v3"))) g.DP = g.NP * 128;
+    }
+    const int NPW = g.DP / 2;   // 32-bit words (disparity pairs) per cost-volume column
     const size_t npix = (size_t)w * h;
     const size_t rowBytes = (size_t)g.W1 * NPW * 4;
     const size_t volBytes = rowBytes * h;
@@ -1873,15 +1890,25 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
         // R3D_HSCAN_ROWS=2 selects the 2-rows-per-wave instantiation for A/B.  D <= 256: 4 x 32 (2 rows per wave).
         static const bool rows2 = [] { const char *e = getenv("R3D_HSCAN_ROWS"); return e && !strcmp(e, "2"); }();
         constexpr int K1 = 12, K1b = 8, K2 = 6;
-        const bool padded = g.D != 128 * g.NP;
-        const bool four = g.NP == 1 && !rows2;
-        const int rpw = four ? 4 : 2, npl = four ? 4 : 2 * g.NP;
-        const int K = four ? K1b : (g.NP == 1 ? K1 : K2);
+        const bool padded = g.D != g.DP;
+        // DP = 64 / 32: still 16 lanes per row and 4 rows per wave (612 waves at C2 height), with 2 / 1 registers per lane and
+        // proportionally longer segments so that a segment stays 128 registers of loads in flight
+        constexpr int K64 = 16, K32 = 32;
+        const bool small = g.DP < 128;
+        const bool four = (g.DP == 128 && !rows2) || small;
+        const int rpw = four ? 4 : 2, npl = g.DP == 32 ? 1 : g.DP == 64 ? 2 : four ? 4 : 2 * g.NP;
+        const int K = g.DP == 32 ? K32 : g.DP == 64 ? K64 : four ? K1b : (g.NP == 1 ? K1 : K2);
         const int nwaves = (h + rpw - 1) / rpw;
         if ((rc = r3d_reserve(ctx, ws.ckpt, (size_t)nwaves * (g.W1 / K + 1) * (npl + 1) * 64 * 4))) return rc;
         const int *cp = (const int *)ws.cost.p;
         int *hp = (int *)ws.hsum.p, *kp = (int *)ws.ckpt.p;
-        if (four) {
+        if (g.DP == 32) {
+            if (padded) k_hscan2<1, 16, K32, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
+            else k_hscan2<1, 16, K32, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
+        } else if (g.DP == 64) {
+            if (padded) k_hscan2<2, 16, K64, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
+            else k_hscan2<2, 16, K64, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
+        } else if (four) {
             if (padded) k_hscan2<4, 16, K1b, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
             else k_hscan2<4, 16, K1b, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
         } else if (g.NP == 1) {

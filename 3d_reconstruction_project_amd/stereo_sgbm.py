@@ -119,7 +119,10 @@ class StereoSGBM:
         minD = self._p["minDisparity"]
         H, W = self._last_shape
         W1 = (W + min(minD, 0)) - max(minD + D, 0)
-        dp = 128 if D <= 128 else 256
+        # slots per cost-volume column: the smallest of 32 / 64 / 128 / 256 that holds D (128 / 256 for the v1 / v3 kernels)
+        import os
+        legacy = os.environ.get("R3D_SGM_IMPL") in ("v1", "v3")
+        dp = next(c for c in ((128, 256) if legacy else (32, 64, 128, 256)) if D <= c)
         out = {}
         cost = np.empty((H, W1, dp), np.int16) if want_cost else None
         hsum = np.empty((H, W1, dp), np.int16) if want_hsum else None
