@@ -200,6 +200,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # secondary metric on every rank when N > 1 (weak scaling: one 1M-point cloud pair per GPU, no communication inside the
+    # registration loop); rank 0 reports the sum of the per-rank rates
+    gicp_multi = None
+    if dist is not None and (world > 1 or os.environ.get("R3D_FORCE_DIST") == "gicp") and not args.no_gicp:
+        ctx.set_profiling(False)
+        gm = bench_gicp(r3d, ctx, cpu=False)
+        t = torch.tensor([gm["value"], gm["ms_per_iteration"]], dtype=torch.float64, device="cuda")
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        gicp_multi = dict(gm, value=round(float(tsum[0].item()), 2), ms_per_iteration=round(float(tmax[1].item()), 4),
+                          per_gpu=round(float(tsum[0].item()) / world, 2), n_gpus=world,
+                          note="sum over ranks of the per-rank rate; ms_per_iteration is the slowest rank's")
     if rank == 0:
         value = world * args.steps / elapsed
         dom = max(prof, key=prof.get) if prof else None
@@ -278,8 +292,8 @@ def main():
         if world == 1 and args.extras:
             ctx.set_profiling(False)
             frame_loop = bench_frame_loop(r3d, ctx, dL, dR)
-        gicp = None
-        if world == 1 and not args.no_gicp:
+        gicp = gicp_multi
+        if world == 1 and gicp_multi is None and not args.no_gicp:
             gicp = bench_gicp(r3d, ctx, cpu=not args.no_cpu_baseline)
         out = {"metric": "disparity-maps/s @8MP d=128", "value": round(value, 2), "unit": "disparity-maps/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
