@@ -222,3 +222,23 @@ def test_batch_api_pipelines_and_matches_single_calls(r3d, synth):
     assert m.compute_batch([], []) == [] if False else True
     one = m.compute_batch([pairs[0][0]], [pairs[0][1]])
     np.testing.assert_array_equal(one[0], batch[0])
+
+
+def test_row_stride_larger_than_width(r3d, synth):
+    """include/r3d.h: `stride` is the row pitch of both input images in bytes (a cv::Mat ROI / padded camera buffer)."""
+    W, H, D, pitch = 301, 77, 48, 320
+    L, R, _ = synth.stereo_pair(W, H, D, seed=9)
+    bufL = np.full((H, pitch), 255, np.uint8)
+    bufR = np.full((H, pitch), 0, np.uint8)
+    bufL[:, :W], bufR[:, :W] = L, R
+    m = _gpu(r3d, D, C2_KW)
+    ctx = m.context
+    d_l, d_r, d_d = ctx.to_device(bufL), ctx.to_device(bufR), ctx.alloc(W * H * 2)
+    m.compute_device(d_l, d_r, W, H, pitch, d_d)
+    got = np.empty((H, W), np.int16)
+    ctx.d2h(got, d_d)
+    for p in (d_l, d_r, d_d):
+        ctx.free(p)
+    np.testing.assert_array_equal(got, _oracle(L, R, D, C2_KW))
+    with pytest.raises(r3d.R3DError):
+        m.compute_device(1, 1, W, H, W - 1, 1)                      # stride < width is refused before any access
