@@ -1889,7 +1889,7 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
         // waves (with 2 rows per wave 1224 waves left 200 SIMDs with double work: makespan 2x the mean);
         // R3D_HSCAN_ROWS=2 selects the 2-rows-per-wave instantiation for A/B.  D <= 256: 4 x 32 (2 rows per wave).
         static const bool rows2 = [] { const char *e = getenv("R3D_HSCAN_ROWS"); return e && !strcmp(e, "2"); }();
-        constexpr int K1 = 12, K1b = 8, K2 = 6;
+        constexpr int K1 = 12, K1b = 16, K2 = 6;
         const bool padded = g.D != g.DP;
         // DP = 64 / 32: still 16 lanes per row and 4 rows per wave (612 waves at C2 height), with 2 / 1 registers per lane and
         // proportionally longer segments so that a segment stays 128 registers of loads in flight
