@@ -266,9 +266,13 @@ __device__ __forceinline__ int trunc_div_small(int n, int d) {
 }
 // smallest integer T with T * a >= thr  (a > 0): S * a < thr  <=>  S < T
 __device__ __forceinline__ int ceil_div_small(int thr, int a, float inv_a) {
+    // |thr| < 2^23 and a <= 100: the float estimate is within one of the answer; two branch-free corrections each way (a
+    // `while` here becomes a divergent loop with exec-mask branches in the middle of the row step)
     int q = (int)floorf((float)thr * inv_a);
-    while (q * a < thr) q++;
-    while ((q - 1) * a >= thr) q--;
+    q += (q * a < thr) ? 1 : 0;
+    q += (q * a < thr) ? 1 : 0;
+    q -= ((q - 1) * a >= thr) ? 1 : 0;
+    q -= ((q - 1) * a >= thr) ? 1 : 0;
     return q;
 }
 
