@@ -1,0 +1,16 @@
+#!/bin/bash
+# Interleaved A/B of two builds of libr3d_hip.so on ONE GPU box: bench.py (no CPU legs) alternately with each library,
+# REPS times.  Kernel times drift by +-6 % over minutes on one box and differ between boxes, so two variants measured one
+# after the other (or in different gpurun calls) cannot be compared below ~10 %; interleaving can.
+# Usage (on the GPU box, from the repository root):  tools/ab_libs.sh /path/libA.so /path/libB.so [REPS]
+set -euo pipefail
+A="$1"; B="$2"; REPS="${3:-4}"
+L=3d_reconstruction_project_amd/lib/libr3d_hip.so
+cp "$L" /tmp/libr3d_keep.so
+trap 'cp /tmp/libr3d_keep.so "$L"' EXIT
+for rep in $(seq "$REPS"); do
+  for v in A B; do
+    if [ $v = A ]; then cp "$A" "$L"; else cp "$B" "$L"; fi
+    python bench.py --no-cpu-baseline --no-gicp 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['value'], d['roofline']['kernel_ms'])"
+  done
+done
