@@ -107,8 +107,5 @@ static inline void r3d_prof_end(r3d_ctx *ctx, r3d_sgm_ws &ws, hipStream_t st) {
 int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p, const uint8_t *d_left, const uint8_t *d_right,
                 int w, int h, int stride, int16_t *d_disp);
 int r3d_selftest_run(r3d_ctx *ctx);
-// sgm.hip compiled with -DR3D_TU_VSCAN (own scheduler strategy, see build.sh): launches k_vscan2, returns a hipError_t
-int r3d_sgm_launch_vscan2(hipStream_t st, const void *geom, float inv_a, const int *cost, const int *cspec, const int *hsum,
-                          int16_t *raw, int16_t *mins);
 int r3d_speckle_run(r3d_ctx *ctx, r3d_sgm_ws &ws, hipStream_t st, int16_t *d_img, int w, int h, int newVal, int maxSize, int maxDiff);
 int r3d_streambench_run(r3d_ctx *ctx, int mode, int rows, size_t row_bytes, int write, int delay, int reps, float *ms);

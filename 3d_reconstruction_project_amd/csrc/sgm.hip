@@ -287,11 +287,6 @@ __device__ __forceinline__ void bt_interval(int vm, int v, int vp, bool has_m, b
     hi = max(max(l, r), v);
 }
 
-// This file is compiled twice (csrc/build.sh): once as is, and once with -DR3D_TU_VSCAN and the ILP-oriented machine
-// scheduler, which then contributes only k_vscan2 and its launcher (the other kernels lose more to the larger register
-// footprint of that scheduler than they gain).  Everything up to here is shared by both translation units.
-#ifndef R3D_TU_VSCAN
-
 __global__ void __launch_bounds__(256) k_fill_s16(int16_t *__restrict__ p, size_t n, int16_t v) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
 }
@@ -1165,8 +1160,6 @@ __global__ void __launch_bounds__(64) k_hscan3(const int *__restrict__ cvol, con
     }
 }
 
-#endif  // !R3D_TU_VSCAN
-
 // ---------------------------------------------------------------------------------------------------------
 // k_vscan2: vertical path + winner-take-all with 16 disparities per lane (NPL = 8): LPC = DP/16 lanes per column,
 // CPW = 64/LPC adjacent columns per wave, each column an independent chain inside its lane group.  Everything after
@@ -1309,8 +1302,6 @@ __global__ void __launch_bounds__(64) k_vscan2(const int *__restrict__ cvol, con
         if (y + 3 < src_end) process(y + 3, c3, h3);
     }
 }
-
-#ifndef R3D_TU_VSCAN
 
 // ---------------------------------------------------------------------------------------------------------
 // k_lrcheck: per row: rebuild OpenCV's disp2 / disp2cost scatter (lowest cost wins, among equal costs the
@@ -1699,19 +1690,12 @@ int launch_cost2(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st,
     }
 }
 
-#endif  // !R3D_TU_VSCAN
 
-}  // namespace
-
-#ifdef R3D_TU_VSCAN
-
-// launcher of k_vscan2 (this translation unit's only export).  geom: the SgmGeom of the call (its type lives in each unit's
-// anonymous namespace, hence the untyped pointer).  Variants: 16 columns per wave (NPL = 16, LPC = 4: 784 waves at C2, no
+// launcher of k_vscan2.  Variants: 16 columns per wave (NPL = 16, LPC = 4: 784 waves at C2, no
 // SIMD carries two; needs whole 32-disparity lanes) is the default where it applies, 8 columns (NPL = 8, LPC = 8) otherwise;
 // R3D_VSCAN_COLS = 4 | 8 | 16 forces one for A/B runs.
-int r3d_sgm_launch_vscan2(hipStream_t st, const void *geom, float inv_a, const int *cost, const int *cspec, const int *hsum,
-                          int16_t *raw, int16_t *mins) {
-    const SgmGeom &g = *(const SgmGeom *)geom;
+int launch_vscan2(hipStream_t st, const SgmGeom &g, float inv_a, const int *cost, const int *cspec, const int *hsum, int16_t *raw,
+                  int16_t *mins) {
     static const int force = [] { const char *e = getenv("R3D_VSCAN_COLS"); return e ? atoi(e) : 0; }();
     if (g.DP == 32) {
         k_vscan2<4, 4><<<dim3((g.W1 + 15) / 16, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins);
@@ -1728,7 +1712,7 @@ int r3d_sgm_launch_vscan2(hipStream_t st, const void *geom, float inv_a, const i
     return (int)hipGetLastError();
 }
 
-#else  // !R3D_TU_VSCAN
+}  // namespace
 
 int r3d_streambench_run(r3d_ctx *ctx, int mode, int rows, size_t row_bytes, int write, int delay, int reps, float *ms) {
     R3D_HIP(ctx, hipSetDevice(ctx->device));
@@ -1934,7 +1918,7 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
             // D <= 128: 8 registers x 8 lanes per column = 8 columns per wave (1568 waves).  R3D_VSCAN_COLS=4 selects
             // 4 registers x 16 lanes (3136 finer-grained waves): measured 1.15 ms against 0.89 ms, the extra
             // cross-lane stages cost more than the better SIMD balance returns.
-            if (int e = r3d_sgm_launch_vscan2(st, &g, inv_a, (const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p,
+            if (int e = launch_vscan2(st, g, inv_a, (const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p,
                                               (int16_t *)ws.raw.p, (int16_t *)ws.mins.p))
                 return r3d_fail(ctx, R3D_E_HIP, "k_vscan2 launch failed: %s", hipGetErrorString((hipError_t)e));
         } else if (g.NP == 1) k_vscan<1, CPW><<<grid, 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
@@ -1955,5 +1939,3 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
     r3d_prof_end(ctx, ws, st);
     return R3D_OK;
 }
-
-#endif  // R3D_TU_VSCAN
