@@ -1693,7 +1693,8 @@ int launch_cost2(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st,
 
 // launcher of k_vscan2.  Variants: 16 columns per wave (NPL = 16, LPC = 4: 784 waves at C2, no
 // SIMD carries two; needs whole 32-disparity lanes) is the default where it applies, 8 columns (NPL = 8, LPC = 8) otherwise;
-// R3D_VSCAN_COLS = 4 | 8 | 16 forces one for A/B runs.
+// R3D_VSCAN_COLS = 4 | 8 | 16 forces one for A/B runs (4 columns: 3136 finer-grained waves, measured 1.15 ms against 0.89 ms for 8:
+// the extra cross-lane stages cost more than the better SIMD balance returns; 16 vs 8: 0.921 vs 0.956 ms interleaved).
 int launch_vscan2(hipStream_t st, const SgmGeom &g, float inv_a, const int *cost, const int *cspec, const int *hsum, int16_t *raw,
                   int16_t *mins) {
     static const int force = [] { const char *e = getenv("R3D_VSCAN_COLS"); return e ? atoi(e) : 0; }();
@@ -1915,11 +1916,9 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
         constexpr int CPW = 8;
         dim3 grid((g.W1 + CPW - 1) / CPW, 4);
         if (!use_v1) {
-            // D <= 128: 8 registers x 8 lanes per column = 8 columns per wave (1568 waves).  R3D_VSCAN_COLS=4 selects
-            // 4 registers x 16 lanes (3136 finer-grained waves): measured 1.15 ms against 0.89 ms, the extra
-            // cross-lane stages cost more than the better SIMD balance returns.
+            // mapping per disparity-slot layout: see launch_vscan2
             if (int e = launch_vscan2(st, g, inv_a, (const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p,
-                                              (int16_t *)ws.raw.p, (int16_t *)ws.mins.p))
+                                      (int16_t *)ws.raw.p, (int16_t *)ws.mins.p))
                 return r3d_fail(ctx, R3D_E_HIP, "k_vscan2 launch failed: %s", hipGetErrorString((hipError_t)e));
         } else if (g.NP == 1) k_vscan<1, CPW><<<grid, 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
         else k_vscan<2, CPW><<<grid, 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
