@@ -102,6 +102,8 @@ void r3d_destroy(r3d_ctx *ctx) {
         if (ws.done) (void)hipEventDestroy(ws.done);
     }
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
+    if (ctx->icp_ev) (void)hipEventDestroy(ctx->icp_ev);
+    if (ctx->icp_host) (void)hipHostFree(ctx->icp_host);
     for (r3d_buf &b : ctx->cloud_bufs)
         if (b.p) (void)hipFree(b.p);
     for (r3d_buf &b : ctx->pp_bufs)

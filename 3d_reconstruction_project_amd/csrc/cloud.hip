@@ -405,7 +405,11 @@ __device__ __forceinline__ void nn_block_global(const GridView &g, double px, do
         const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
         const bool ok = xok && z >= 0 && z < g.nz && y >= 0 && y < g.ny;
         const int64_t row = ((int64_t)min(max(z, 0), g.nz - 1) * g.ny + min(max(y, 0), g.ny - 1)) * g.nx;
-        const int b = g.cstart[row + x0], e = g.cstart[row + x1 + 1];
+        // both bounds of the run with ONE 16-byte request (the end entry is at most three behind the start entry; the table
+        // is allocated with four spare entries); the search is bound by the number of cache-line requests, not by latency
+        typedef int int4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte global load
+        const int4_a4 cs = *(const int4_a4 *)(g.cstart + row + x0);
+        const int b = cs.x, de = x1 + 1 - x0, e = de == 3 ? cs.w : de == 2 ? cs.z : cs.y;
         rb[r] = b;
         re[r] = b + ((e - b) & (ok ? -1 : 0));
     }
@@ -833,7 +837,7 @@ int grid_build(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, doubl
     rc = sort_by_cell(ctx, ar, d_pts, n, G.mn, cell, dims, 0, &G.keys, &idx);
     if (rc) return rc;
     int *cnt = (int *)ar.get((size_t)(G.ncells + 1) * 4), *rs = (int *)ar.get((size_t)(G.ncells + 1) * 4);
-    int *cs = (int *)ar.get((size_t)(G.ncells + 1) * 4);
+    int *cs = (int *)ar.get((size_t)(G.ncells + 1 + 4) * 4);   // + 4: nn_block_global reads 16 bytes at a run's first cell
     double *sorted = (double *)ar.get((size_t)n * 24);
     if (ar.rc) return ar.rc;
     R3D_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)(G.ncells + 1) * 4, ctx->stream));
@@ -1125,7 +1129,9 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
     const int nblocks = tiled_impl ? (int)std::min<int64_t>((ns + 63) / 64, 8192) : (int)std::min<int64_t>((ns + ICP_BLOCK - 1) / ICP_BLOCK, 2048);
     double *d_part = (double *)ar.get((size_t)nblocks * ICP_SLOTS * 8), *d_sum = (double *)ar.get(ICP_SLOTS * 8);
     if (ar.rc) return ar.rc;
-    double sums[ICP_SLOTS];
+    if (!ctx->icp_ev) R3D_HIP(ctx, hipEventCreateWithFlags(&ctx->icp_ev, hipEventDisableTiming));
+    if (!ctx->icp_host) R3D_HIP(ctx, hipHostMalloc((void **)&ctx->icp_host, ICP_SLOTS * sizeof(double), hipHostMallocDefault));
+    double *sums = ctx->icp_host;   // pinned: the per-iteration D2H copy is a plain DMA, completion seen by polling the event
     auto eval = [&](const double Tm[16]) -> int {
         Rigid R = to_rigid(Tm);
         const double eps = p->gicp_epsilon > 0 ? p->gicp_epsilon : 1e-3;
@@ -1145,8 +1151,15 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
         }
         k_icp_final<<<ICP_SLOTS, 64, 0, ctx->stream>>>(d_part, nblocks, d_sum);
         R3D_HIP(ctx, hipGetLastError());
-        R3D_HIP(ctx, hipMemcpyAsync(sums, d_sum, sizeof sums, hipMemcpyDeviceToHost, ctx->stream));
-        R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        R3D_HIP(ctx, hipMemcpyAsync(sums, d_sum, ICP_SLOTS * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        // one host round trip per iteration: poll an event instead of a blocking stream synchronise (the blocking wait may put
+        // the thread to sleep for a scheduler tick: occasional 40-50 ms iterations in an otherwise 0.26 ms loop)
+        R3D_HIP(ctx, hipEventRecord(ctx->icp_ev, ctx->stream));
+        for (;;) {
+            const hipError_t q = hipEventQuery(ctx->icp_ev);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return r3d_fail(ctx, R3D_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+        }
         return R3D_OK;
     };
     R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -56,6 +56,8 @@ struct r3d_ctx {
     int n_acc = 0;
     // cloud workspace (cloud.hip)
     std::vector<r3d_buf> cloud_bufs;
+    hipEvent_t icp_ev = nullptr;   // polled once per registration iteration
+    double *icp_host = nullptr;    // pinned landing buffer of the per-iteration sums
     // pre/post-processing workspace (prepost.hip)
     std::vector<r3d_buf> pp_bufs;
     r3d_buf pp_minmax, pp_lut;
