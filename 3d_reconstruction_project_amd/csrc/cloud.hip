@@ -29,6 +29,10 @@ struct GridView {
                            // x is the fastest key digit, so cells adjacent in x hold ONE contiguous run of points
     const double *pts;     // [n][3] points in cell-sorted order
     const int *idx;        // [n] sorted slot -> original index
+    // optional float32 structure-of-arrays copy of pts (n + 4 entries each) for the two-stage 1-NN search of the
+    // registration loop; fe = 2 x (bound on |float distance - exact distance|), see nn_block_top4
+    const float *fx, *fy, *fz;
+    float fe;
 };
 
 __device__ __forceinline__ int cell_coord(double v, double o, double inv) { return (int)floor((v - o) * inv); }
@@ -436,6 +440,92 @@ __device__ __forceinline__ void nn_block_global(const GridView &g, double px, do
     }
 }
 
+// Two-stage form of the same search.  The loop is bound by the texture-addresser / L1 path (PMC: 4.4 M gather instructions
+// per iteration at 1 M points, the L2 sees only 4.6 M requests), and a float64 candidate costs two gather instructions
+// (24 bytes = dwordx4 + dwordx2).  Stage 1 scans float32 structure-of-arrays copies (three 16-byte gathers per FOUR
+// candidates) and keeps the four smallest float distances with their slots -- branch-free, so no lane waits for another
+// lane's exact arithmetic.  Stage 2 evaluates the best three exactly (float64, the update rule and tie order of
+// nn_block_global), every lane doing the same three steps.  With |d_float - d_exact| <= fe/2 for every candidate (coordinate
+// rounding of target and query; bound from the bounding box, computed on the host) every candidate that can be the exact
+// nearest point, or tie with it, has a float distance within fe of the smallest float distance; if the FOURTH smallest is
+// within that margin too, the three may not contain them all and the lane falls back to the all-float64 scan (rare: four
+// candidates within micrometres of the same distance).  Result: identical to nn_block_global.
+__device__ __forceinline__ void nn_block_top4(const GridView &g, double px, double py, double pz, int cx, int cy, int cz, double &best,
+                                              int &bi) {
+    const int xa = cx - 1, xb = cx + 1;
+    const bool xok = xb >= 0 && xa <= g.nx - 1;
+    const int x0 = min(max(xa, 0), g.nx - 1), x1 = min(max(xb, 0), g.nx - 1);
+    typedef int int4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float float4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    int rb[9], re[9];
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+        const bool ok = xok && z >= 0 && z < g.nz && y >= 0 && y < g.ny;
+        const int64_t row = ((int64_t)min(max(z, 0), g.nz - 1) * g.ny + min(max(y, 0), g.ny - 1)) * g.nx;
+        const int4_a4 cs = *(const int4_a4 *)(g.cstart + row + x0);
+        const int b = cs.x, de = x1 + 1 - x0, e = de == 3 ? cs.w : de == 2 ? cs.z : cs.y;
+        rb[r] = b;
+        re[r] = b + ((e - b) & (ok ? -1 : 0));
+    }
+    const float qx = (float)px, qy = (float)py, qz = (float)pz;
+    const float INF = __builtin_huge_valf();
+    float t1 = INF, t2 = INF, t3 = INF, t4 = INF;
+    int i1 = -1, i2 = -1, i3 = -1;
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        const int e = re[r];
+        for (int j0 = rb[r]; j0 < e; j0 += 4) {
+            const float4_a4 X = *(const float4_a4 *)(g.fx + j0), Y = *(const float4_a4 *)(g.fy + j0), Z = *(const float4_a4 *)(g.fz + j0);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + u;
+                const float fdx = X[u] - qx, fdy = Y[u] - qy, fdz = Z[u] - qz;
+                float f = fdx * fdx + fdy * fdy + fdz * fdz;
+                f = j < e ? f : INF;
+                // insert (f, j) into the ascending quadruple; the slot of the fourth is never needed
+                const bool c3 = f < t3, c2 = f < t2, c1 = f < t1;
+                t4 = c3 ? t3 : fminf(t4, f);
+                i3 = c2 ? i2 : (c3 ? j : i3);
+                t3 = c2 ? t2 : (c3 ? f : t3);
+                i2 = c1 ? i1 : (c2 ? j : i2);
+                t2 = c1 ? t1 : (c2 ? f : t2);
+                i1 = c1 ? j : i1;
+                t1 = c1 ? f : t1;
+            }
+        }
+    }
+    if (!(t1 < INF)) return;                       // empty block: nothing to evaluate (the caller goes on to the outer shells)
+    const float tt = sqrtf(t1) * 1.000001f + g.fe;  // the relative term covers the float32 evaluation of the distance itself
+    const float thr2 = tt * tt * 1.000001f;
+    if (t4 <= thr2) {                              // a fourth contender: the triple may be incomplete
+        nn_block_global(g, px, py, pz, cx, cy, cz, best, bi);
+        return;
+    }
+    const int cand[3] = {i1, i2, i3};
+    const float ct[3] = {t1, t2, t3};
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int j = max(cand[q], 0);             // clamped slot: no branch around the loads
+        const double dx = g.pts[(int64_t)j * 3] - px, dy = g.pts[(int64_t)j * 3 + 1] - py, dz = g.pts[(int64_t)j * 3 + 2] - pz;
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        if (cand[q] >= 0 && ct[q] <= thr2 && d2 <= best) {
+            if (d2 < best || (bi >= 0 && g.idx[j] < g.idx[bi])) { best = d2; bi = j; }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_soa_f32(const double *__restrict__ pts, int64_t n, float *__restrict__ fx, float *__restrict__ fy,
+                                                 float *__restrict__ fz) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n + 4) return;
+    const bool in = i < n;
+    const int64_t ic = in ? i : n - 1;
+    fx[i] = in ? (float)pts[ic * 3] : 0.f;
+    fy[i] = in ? (float)pts[ic * 3 + 1] : 0.f;
+    fz[i] = in ? (float)pts[ic * 3 + 2] : 0.f;
+}
+
 // shells 2.. of the search (only queries whose nearest point is further than one cell away get here)
 __device__ __forceinline__ void nn_outer_shells(const GridView &g, double px, double py, double pz, int cx, int cy, int cz, int smax,
                                                 double &best, int &bi) {
@@ -548,7 +638,8 @@ __global__ void __launch_bounds__(ICP_BLOCK) k_icp_eval(GridView g, const double
         const int cx = cell_coord(px, g.ox, g.inv_cell), cy = cell_coord(py, g.oy, g.inv_cell), cz = cell_coord(pz, g.oz, g.inv_cell);
         double best = r2;
         int bi = -1;
-        nn_block_global(g, px, py, pz, cx, cy, cz, best, bi);
+        if (g.fx) nn_block_top4(g, px, py, pz, cx, cy, cz, best, bi);   // wave-uniform choice
+        else nn_block_global(g, px, py, pz, cx, cy, cz, best, bi);
         nn_outer_shells(g, px, py, pz, cx, cy, cz, smax, best, bi);
         if (corr) corr[i] = bi >= 0 ? g.idx[bi] : -1;
         if (bi >= 0) icp_accumulate<MODE>(g, src_n, tgt_n, i, T, eps, px, py, pz, best, bi, acc);
@@ -853,7 +944,7 @@ int grid_build(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, doubl
     }
     k_gather3<<<nb, 256, 0, ctx->stream>>>(d_pts, idx, n, sorted);
     R3D_HIP(ctx, hipGetLastError());
-    G.v = GridView{G.mn[0], G.mn[1], G.mn[2], cell, 1.0 / cell, dims[0], dims[1], dims[2], cs, sorted, idx};
+    G.v = GridView{G.mn[0], G.mn[1], G.mn[2], cell, 1.0 / cell, dims[0], dims[1], dims[2], cs, sorted, idx, nullptr, nullptr, nullptr, 0.f};
     return R3D_OK;
 }
 
@@ -1091,6 +1182,24 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
     int rc;
     Grid G;
     if ((rc = grid_build(ctx, ar, d_t, nt, p->max_correspondence_distance, 3.0, G))) return rc;
+    // float32 copy for the two-stage search (R3D_ICP_IMPL=exact: all-float64 search, for A/B).  fe = 2 x bound on
+    // |float distance - exact distance|: both end points are rounded to float (relative 2^-24 per coordinate), times a
+    // safety factor of 2; skipped (exact search) when the coordinates are so large that the margin stops filtering.
+    {
+        const char *ie = getenv("R3D_ICP_IMPL");
+        double M = 0;
+        for (int a = 0; a < 3; a++) M = std::max(M, std::max(std::fabs(G.mn[a]), std::fabs(G.mx[a])));
+        const double Mq = M + 2.0 * p->max_correspondence_distance + G.v.cell;
+        const double e = std::sqrt(3.0) * (M + Mq) * std::ldexp(1.0, -24);
+        if (!(ie && strcmp(ie, "exact") == 0) && 4.0 * e < 0.25 * G.v.cell && M < 1e30) {
+            float *f = (float *)ar.get((size_t)(nt + 4) * 3 * sizeof(float));
+            if (ar.rc) return ar.rc;
+            k_soa_f32<<<(unsigned)((nt + 4 + 255) / 256), 256, 0, ctx->stream>>>(G.v.pts, nt, f, f + (nt + 4), f + 2 * (nt + 4));
+            R3D_HIP(ctx, hipGetLastError());
+            G.v.fx = f; G.v.fy = f + (nt + 4); G.v.fz = f + 2 * (nt + 4);
+            G.v.fe = (float)(4.0 * e);
+        }
+    }
     double *d_tns = nullptr;
     if (d_tn) {
         d_tns = (double *)ar.get((size_t)nt * 24);
@@ -1121,7 +1230,8 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
             d_sn = d_sns;
         }
     }
-    // default: per-lane search straight from global memory (L1/L2-cached gathers); R3D_ICP_IMPL=tiled selects the LDS-tiled
+    // default: per-lane search straight from global memory (L1/L2-cached gathers), two-stage (float32 top-4, exact top-3:
+    // nn_block_top4; R3D_ICP_IMPL=exact keeps every distance in float64); R3D_ICP_IMPL=tiled selects the LDS-tiled
     // kernel, kept for A/B: measured 0.31 vs 0.26 ms per GICP iteration at 1M points (staging + barriers cost more than
     // the gathers they replace once the source is Morton-ordered)
     const char *impl_env = getenv("R3D_ICP_IMPL");

@@ -258,7 +258,8 @@ def test_orient_normals_makes_a_closed_surface_consistent(r3d):
 
 
 def test_lds_tiled_search_kernel_matches_default():
-    """R3D_ICP_IMPL=tiled selects the LDS-tiled correspondence kernel (kept for A/B): same candidates in the same order,
+    """R3D_ICP_IMPL=exact (all-float64 search) and =tiled (LDS-tiled all-float64 search) are kept for A/B beside the default
+    two-stage search.  tiled: same candidates in the same order,
     so the correspondence counts are identical; the sums are reduced in a different order (per wave instead of per
     256-thread block), so transforms agree to rounding (1e-12), in every mode."""
     import os
@@ -276,16 +277,19 @@ def test_lds_tiled_search_kernel_matches_default():
         "    r = r3d.cloud_ops.registration(src, tgt, 0.02, mode=mode, max_iteration=6, source_normals=sn, target_normals=tn)\n"
         "    print('RES', mode, r['T'].tobytes().hex(), r['correspondences'], repr(r['inlier_rmse']))\n")
     outs = []
-    for impl in ("global", "tiled"):
+    for impl in ("exact", "tiled", "default"):
         env = dict(os.environ, R3D_ICP_IMPL=impl)
         o = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
         lines = [ln.split() for ln in o.stdout.splitlines() if ln.startswith("RES")]
         assert len(lines) == 3, o.stdout + o.stderr
         outs.append(lines)
-    for a, b in zip(*outs):
+    for a, b in zip(outs[0], outs[1]):
         assert a[3] == b[3] and int(a[3]) > 50000                                     # correspondences
         Ta, Tb = (np.frombuffer(bytes.fromhex(x[2])).reshape(4, 4) for x in (a, b))
         assert np.abs(Ta - Tb).max() < 1e-12 and abs(float(a[4]) - float(b[4])) < 1e-12
+    # the default two-stage search (float32 top-4, then exact top-3) finds exactly the correspondences of the all-float64
+    # search and sums them in the same order: bit-identical transforms
+    assert outs[0] == outs[2]
 
 
 def test_non_finite_coordinates_are_refused(r3d):
