@@ -26,7 +26,7 @@
  * this library.  The product path (lib3d_reconstruction_project_amd HIP library)
  * never calls it.
  *
- * Build: make -C oracle     (gcc -O3 -march=native -fopenmp -shared)
+ * Build: make -C oracle     (gcc -O3 -march=x86-64-v3 -fopenmp -shared)
  */
 #include <limits.h>
 #include <stddef.h>
