@@ -23,7 +23,8 @@ def test_reproject_disparity_matches_formula(r3d):
     d = disp[v, u] / 16.0
     h = np.stack([u, v, d, np.ones_like(d)], 0).astype(np.float64)
     X = (Q[:, 0:1] * h[0] + Q[:, 1:2] * h[1]) + Q[:, 2:3] * h[2] + Q[:, 3:4] * h[3]
-    want = (X[:3] / X[3]).T
+    with np.errstate(divide="ignore", invalid="ignore"):          # disparity 0 reprojects to infinity (W = 0), as in cv2
+        want = (X[:3] / X[3]).T
     finite = np.isfinite(want).all(1)
     assert np.abs(pts[finite] - want[finite]).max() <= 1e-9 * np.abs(want[finite]).max()
     empty = r3d.cloud_ops.reproject_disparity(np.full((10, 20), -16, np.int16), Q, 0)
