@@ -33,6 +33,9 @@ struct GridView {
     // registration loop; fe = 2 x (bound on |float distance - exact distance|), see nn_block_top4
     const float *fx, *fy, *fz;
     float fe;
+    // optional packed copy for the default search (nn_block_q10): one dword per sorted point = 10-bit offsets inside its own
+    // cell (x | y << 10 | z << 20) and the low two bits of its cell x index (<< 30); n + 4 entries
+    const unsigned *q10;
 };
 
 __device__ __forceinline__ int cell_coord(double v, double o, double inv) { return (int)floor((v - o) * inv); }
@@ -526,6 +529,140 @@ __global__ void __launch_bounds__(256) k_soa_f32(const double *__restrict__ pts,
     fz[i] = in ? (float)pts[ic * 3 + 2] : 0.f;
 }
 
+// Packed form of the two-stage search (the default).  Stage 1 of nn_block_top4 costs three 16-byte gathers per four candidates
+// and walks all nine runs of the 3x3x3 block, every run for as long as its longest lane.  Here
+//  (1) a candidate is ONE dword: its position inside its own cell quantised to 10 bits per axis plus the low two bits of its
+//      cell x index (k_pack_q10), so one 16-byte gather brings four candidates; the query is expressed in the same unit
+//      (cell / 1024) relative to the corner of its 3x3x3 block, where every coordinate is below 3072 and float32 is exact
+//      to 2^-12 units.  Reconstruction error of a candidate: half a unit per axis, so |d_stage1 - d_exact| <= 0.867 units
+//      and the margin (FEQ, "fe" of nn_block_top4) is 1.75 units = cell / 585 -- wide enough to be a bound, narrow enough
+//      that a fourth contender inside it stays a once-in-millions event on real clouds;
+//  (2) runs are visited centre row first, and a row whose slab distance to the query exceeds the current margin threshold
+//      (or the correspondence radius) is skipped: it cannot hold the nearest point, a tie with it, or a contender that the
+//      fallback test would have to count;
+//  (3) every lane keeps its own list of non-empty runs (LDS, column per thread) and walks it in ONE loop, so a wave iterates
+//      max-over-lanes of the per-lane total instead of the sum over runs of the per-run maximum.
+// Stage 2 (exact float64 evaluation of the best three, fallback to nn_block_global on a fourth contender) is unchanged, and
+// so is the result: bit-identical to the all-float64 search (tests/test_cloud_gpu.py).
+constexpr float FEQ = 1.75f;
+
+__global__ void __launch_bounds__(256) k_pack_q10(GridView g, int64_t n, unsigned *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n + 4) return;
+    unsigned w = 0;
+    if (i < n) {
+        const double u[3] = {(g.pts[i * 3] - g.ox) * g.inv_cell, (g.pts[i * 3 + 1] - g.oy) * g.inv_cell, (g.pts[i * 3 + 2] - g.oz) * g.inv_cell};
+        const int dims[3] = {g.nx, g.ny, g.nz};
+        int c0 = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const int c = min(max((int)floor(u[a]), 0), dims[a] - 1);   // the cell the point was sorted into (k_cell_keys)
+            const int q = min(max((int)floor((u[a] - c) * 1024.0), 0), 1023);
+            w |= (unsigned)q << (10 * a);
+            if (a == 0) c0 = c;
+        }
+        w |= (unsigned)(c0 & 3) << 30;
+    }
+    out[i] = w;
+}
+
+__device__ __forceinline__ void nn_block_q10(const GridView &g, double px, double py, double pz, int cx, int cy, int cz, double r2,
+                                             double &best, int &bi, int *__restrict__ sRun /* [27][ICP_BLOCK] */) {
+    constexpr int B = 256;   // = ICP_BLOCK (declared below)
+    const int tid = threadIdx.x;
+    const int xa = cx - 1, xb = cx + 1;
+    const bool xok = xb >= 0 && xa <= g.nx - 1;
+    const int x0 = min(max(xa, 0), g.nx - 1), x1 = min(max(xb, 0), g.nx - 1);
+    typedef int int4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    typedef unsigned uint4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    constexpr int ORD[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};   // centre row, the four rows sharing a face with it, the four corners
+    int rb[9], re[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+        const int r = ORD[q];
+        const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+        const bool ok = xok && z >= 0 && z < g.nz && y >= 0 && y < g.ny;
+        const int64_t row = ((int64_t)min(max(z, 0), g.nz - 1) * g.ny + min(max(y, 0), g.ny - 1)) * g.nx;
+        const int4_a4 cs = *(const int4_a4 *)(g.cstart + row + x0);
+        const int b = cs.x, de = x1 + 1 - x0, e = de == 3 ? cs.w : de == 2 ? cs.z : cs.y;
+        rb[q] = b;
+        re[q] = b + ((e - b) & (ok ? -1 : 0));
+    }
+    int nr = 0;
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+        if (re[q] > rb[q]) {
+            sRun[(nr * 3) * B + tid] = rb[q];
+            sRun[(nr * 3 + 1) * B + tid] = re[q];
+            sRun[(nr * 3 + 2) * B + tid] = ORD[q];
+            nr++;
+        }
+    }
+    // the query in units of cell / 1024 relative to the block corner (cx-1, cy-1, cz-1): [1024, 2048) on every axis
+    const double ux = (px - g.ox) * g.inv_cell, uy = (py - g.oy) * g.inv_cell, uz = (pz - g.oz) * g.inv_cell;
+    const float qxc = (float)((ux - (double)(cx - 1)) * 1024.0), qyc = (float)((uy - (double)(cy - 1)) * 1024.0),
+                qzc = (float)((uz - (double)(cz - 1)) * 1024.0);
+    const float qx = qxc - 0.5f;          // candidates are reconstructed at the centre of their quantisation step
+    const int xm1 = cx - 1;
+    const float INF = __builtin_huge_valf();
+    auto thr_of = [&](float t) { const float tt = sqrtf(t) * 1.000001f + FEQ; return tt * tt * 1.000001f; };
+    const float thr_r = thr_of((float)(r2 * g.inv_cell * g.inv_cell * (1024.0 * 1024.0)) * 1.000001f);
+    float t1 = INF, t2 = INF, t3 = INF, t4 = INF;
+    int i1 = -1, i2 = -1, i3 = -1;
+    int k = 0, j0 = 0, e = 0;
+    float qyr = 0.f, qzr = 0.f;
+    for (;;) {
+        if (j0 >= e) {
+            const float thr = fminf(thr_r, thr_of(t1));
+            while (j0 >= e && k < nr) {
+                const int b_ = sRun[(k * 3) * B + tid], e_ = sRun[(k * 3 + 1) * B + tid], r = sRun[(k * 3 + 2) * B + tid];
+                k++;
+                const int rz = (r * 11) >> 5, ry = r - 3 * rz;
+                const float ylo = 1024.f * (float)ry, zlo = 1024.f * (float)rz;
+                const float sy = fmaxf(0.f, fmaxf(ylo - qyc, qyc - (ylo + 1024.f))), sz = fmaxf(0.f, fmaxf(zlo - qzc, qzc - (zlo + 1024.f)));
+                if (sy * sy + sz * sz <= thr) { j0 = b_; e = e_; qyr = qyc - 0.5f - ylo; qzr = qzc - 0.5f - zlo; }
+            }
+            if (j0 >= e) break;
+        }
+        const uint4_a4 W = *(const uint4_a4 *)(g.q10 + j0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u;
+            const unsigned w = W[u];
+            const int xi = (int)((((w >> 30) - (unsigned)xm1) & 3u) << 10 | (w & 1023u));
+            const float fdx = (float)xi - qx, fdy = (float)((w >> 10) & 1023u) - qyr, fdz = (float)((w >> 20) & 1023u) - qzr;
+            float f = fdx * fdx + fdy * fdy + fdz * fdz;
+            f = j < e ? f : INF;
+            const bool c3 = f < t3, c2 = f < t2, c1 = f < t1;
+            t4 = c3 ? t3 : fminf(t4, f);
+            i3 = c2 ? i2 : (c3 ? j : i3);
+            t3 = c2 ? t2 : (c3 ? f : t3);
+            i2 = c1 ? i1 : (c2 ? j : i2);
+            t2 = c1 ? t1 : (c2 ? f : t2);
+            i1 = c1 ? j : i1;
+            t1 = c1 ? f : t1;
+        }
+        j0 += 4;
+    }
+    if (!(t1 < INF)) return;                       // nothing scanned: the caller goes on to the outer shells
+    const float thr2 = thr_of(t1);
+    if (t4 <= thr2) {                              // a fourth contender: the triple may be incomplete
+        nn_block_global(g, px, py, pz, cx, cy, cz, best, bi);
+        return;
+    }
+    const int cand[3] = {i1, i2, i3};
+    const float ct[3] = {t1, t2, t3};
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int j = max(cand[q], 0);
+        const double dx = g.pts[(int64_t)j * 3] - px, dy = g.pts[(int64_t)j * 3 + 1] - py, dz = g.pts[(int64_t)j * 3 + 2] - pz;
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        if (cand[q] >= 0 && ct[q] <= thr2 && d2 <= best) {
+            if (d2 < best || (bi >= 0 && g.idx[j] < g.idx[bi])) { best = d2; bi = j; }
+        }
+    }
+}
+
 // shells 2.. of the search (only queries whose nearest point is further than one cell away get here)
 __device__ __forceinline__ void nn_outer_shells(const GridView &g, double px, double py, double pz, int cx, int cy, int cz, int smax,
                                                 double &best, int &bi) {
@@ -620,11 +757,14 @@ __device__ __forceinline__ void icp_accumulate(const GridView &g, const double *
     
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(ICP_BLOCK) k_icp_eval(GridView g, const double *__restrict__ src, const double *__restrict__ src_n,
+enum { SEARCH_EXACT = 0, SEARCH_F32 = 1, SEARCH_Q10 = 2 };
+template <int MODE, int SEARCH>
+__global__ void __launch_bounds__(ICP_BLOCK, 3) k_icp_eval(GridView g, const double *__restrict__ src, const double *__restrict__ src_n,
                                                         const double *__restrict__ tgt_n /* cell-sorted order */, int64_t ns, Rigid T,
                                                         double max_dist, double eps, double *__restrict__ partial,
                                                         int *__restrict__ corr /* optional [ns] target original index or -1 */) {
+    static_assert(ICP_BLOCK == 256, "nn_block_q10 assumes 256 threads");
+    __shared__ int sRun[SEARCH == SEARCH_Q10 ? 27 * ICP_BLOCK : 1];
     double acc[ICP_SLOTS];
 #pragma unroll
     for (int q = 0; q < ICP_SLOTS; q++) acc[q] = 0;
@@ -638,7 +778,8 @@ __global__ void __launch_bounds__(ICP_BLOCK) k_icp_eval(GridView g, const double
         const int cx = cell_coord(px, g.ox, g.inv_cell), cy = cell_coord(py, g.oy, g.inv_cell), cz = cell_coord(pz, g.oz, g.inv_cell);
         double best = r2;
         int bi = -1;
-        if (g.fx) nn_block_top4(g, px, py, pz, cx, cy, cz, best, bi);   // wave-uniform choice
+        if (SEARCH == SEARCH_Q10) nn_block_q10(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun);
+        else if (SEARCH == SEARCH_F32) nn_block_top4(g, px, py, pz, cx, cy, cz, best, bi);
         else nn_block_global(g, px, py, pz, cx, cy, cz, best, bi);
         nn_outer_shells(g, px, py, pz, cx, cy, cz, smax, best, bi);
         if (corr) corr[i] = bi >= 0 ? g.idx[bi] : -1;
@@ -944,7 +1085,7 @@ int grid_build(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, doubl
     }
     k_gather3<<<nb, 256, 0, ctx->stream>>>(d_pts, idx, n, sorted);
     R3D_HIP(ctx, hipGetLastError());
-    G.v = GridView{G.mn[0], G.mn[1], G.mn[2], cell, 1.0 / cell, dims[0], dims[1], dims[2], cs, sorted, idx, nullptr, nullptr, nullptr, 0.f};
+    G.v = GridView{G.mn[0], G.mn[1], G.mn[2], cell, 1.0 / cell, dims[0], dims[1], dims[2], cs, sorted, idx, nullptr, nullptr, nullptr, 0.f, nullptr};
     return R3D_OK;
 }
 
@@ -1008,17 +1149,39 @@ void umeyama_from_sums(const double *s /*ICP slots*/, double U[16]) {
         for (int r = 0; r < 3; r++) Vs[r][c] = V[r][ord[c]];
         sv[c] = sqrt(std::max(StS[ord[c]][ord[c]], 0.0));
     }
+    int rank = 0;   // singular values are in descending order: the deficient columns come last
     for (int c = 0; c < 3; c++) {
         double u[3] = {0, 0, 0};
         for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) u[r] += sigma[r][k] * Vs[k][c];
         double l = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-        if (l > 1e-300 && sv[c] > 1e-14 * std::max(sv[0], 1e-300)) for (int r = 0; r < 3; r++) Us[r][c] = u[r] / l;
-        else {  // rank-deficient: complete the basis
-            const int a = (c + 1) % 3, b = (c + 2) % 3;
-            Us[0][c] = Us[1][a] * Us[2][b] - Us[2][a] * Us[1][b];
-            Us[1][c] = Us[2][a] * Us[0][b] - Us[0][a] * Us[2][b];
-            Us[2][c] = Us[0][a] * Us[1][b] - Us[1][a] * Us[0][b];
+        if (!(l > 1e-300 && sv[c] > 1e-14 * std::max(sv[0], 1e-300))) break;
+        for (int r = 0; r < 3; r++) Us[r][c] = u[r] / l;
+        rank = c + 1;
+    }
+    if (rank == 2) {          // planar correspondences: third left vector completes a right-handed basis
+        Us[0][2] = Us[1][0] * Us[2][1] - Us[2][0] * Us[1][1];
+        Us[1][2] = Us[2][0] * Us[0][1] - Us[0][0] * Us[2][1];
+        Us[2][2] = Us[0][0] * Us[1][1] - Us[1][0] * Us[0][1];
+    } else if (rank == 0) {   // one pair, or all pairs coincident: pure translation (an SVD of the zero matrix is U = V = I)
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Us[r][c] = Vs[r][c];
+    } else if (rank == 1) {   // collinear pairs: the twist about the line is undetermined; take the smallest rotation v0 -> u0
+        const double v0[3] = {Vs[0][0], Vs[1][0], Vs[2][0]}, u0[3] = {Us[0][0], Us[1][0], Us[2][0]};
+        const double cs = v0[0] * u0[0] + v0[1] * u0[1] + v0[2] * u0[2];
+        double Rm[3][3];
+        if (cs > -1 + 1e-12) {
+            const double w[3] = {v0[1] * u0[2] - v0[2] * u0[1], v0[2] * u0[0] - v0[0] * u0[2], v0[0] * u0[1] - v0[1] * u0[0]};
+            const double K[3][3] = {{0, -w[2], w[1]}, {w[2], 0, -w[0]}, {-w[1], w[0], 0}};
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) {
+                    double k2 = 0;
+                    for (int k = 0; k < 3; k++) k2 += K[i][k] * K[k][j];
+                    Rm[i][j] = (i == j) + K[i][j] + k2 / (1 + cs);
+                }
+        } else {                // opposite directions: half turn about the second right vector (orthogonal to v0)
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rm[i][j] = 2 * Vs[i][1] * Vs[j][1] - (i == j);
         }
+        for (int c = 1; c < 3; c++)
+            for (int r = 0; r < 3; r++) Us[r][c] = Rm[r][0] * Vs[0][c] + Rm[r][1] * Vs[1][c] + Rm[r][2] * Vs[2][c];
     }
     double S[3] = {1, 1, 1};
     if (det3(Us) * det3(Vs) < 0) S[2] = -1;
@@ -1191,7 +1354,15 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
         for (int a = 0; a < 3; a++) M = std::max(M, std::max(std::fabs(G.mn[a]), std::fabs(G.mx[a])));
         const double Mq = M + 2.0 * p->max_correspondence_distance + G.v.cell;
         const double e = std::sqrt(3.0) * (M + Mq) * std::ldexp(1.0, -24);
-        if (!(ie && strcmp(ie, "exact") == 0) && 4.0 * e < 0.25 * G.v.cell && M < 1e30) {
+        const bool want_f32 = ie && strcmp(ie, "f32") == 0, want_exact = ie && (strcmp(ie, "exact") == 0 || strcmp(ie, "tiled") == 0);
+        // packed search (default): the cell-relative quantisation needs (p - origin) / cell exact to well below 1/1024
+        if (!want_f32 && !want_exact && Mq / G.v.cell < 1e9) {
+            unsigned *q = (unsigned *)ar.get((size_t)(nt + 4) * sizeof(unsigned));
+            if (ar.rc) return ar.rc;
+            G.v.q10 = q;
+            k_pack_q10<<<(unsigned)((nt + 4 + 255) / 256), 256, 0, ctx->stream>>>(G.v, nt, q);
+            R3D_HIP(ctx, hipGetLastError());
+        } else if (!want_exact && 4.0 * e < 0.25 * G.v.cell && M < 1e30) {
             float *f = (float *)ar.get((size_t)(nt + 4) * 3 * sizeof(float));
             if (ar.rc) return ar.rc;
             k_soa_f32<<<(unsigned)((nt + 4 + 255) / 256), 256, 0, ctx->stream>>>(G.v.pts, nt, f, f + (nt + 4), f + 2 * (nt + 4));
@@ -1253,11 +1424,18 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
                 default: k_icp_eval_t<MODE_GICP><<<nblocks, 64, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, md, eps, d_part, nullptr); break;
             }
         } else {
-            switch (p->mode) {
-                case MODE_P2P: k_icp_eval<MODE_P2P><<<nblocks, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, md, eps, d_part, nullptr); break;
-                case MODE_P2PLANE: k_icp_eval<MODE_P2PLANE><<<nblocks, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, md, eps, d_part, nullptr); break;
-                default: k_icp_eval<MODE_GICP><<<nblocks, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, md, eps, d_part, nullptr); break;
-            }
+#define R3D_ICP_LAUNCH(M, S) k_icp_eval<M, S><<<nblocks, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, R, md, eps, d_part, nullptr)
+#define R3D_ICP_MODES(S)                                            \
+    switch (p->mode) {                                              \
+        case MODE_P2P: R3D_ICP_LAUNCH(MODE_P2P, S); break;          \
+        case MODE_P2PLANE: R3D_ICP_LAUNCH(MODE_P2PLANE, S); break;  \
+        default: R3D_ICP_LAUNCH(MODE_GICP, S); break;               \
+    }
+            if (G.v.q10) { R3D_ICP_MODES(SEARCH_Q10) }
+            else if (G.v.fx) { R3D_ICP_MODES(SEARCH_F32) }
+            else { R3D_ICP_MODES(SEARCH_EXACT) }
+#undef R3D_ICP_MODES
+#undef R3D_ICP_LAUNCH
         }
         k_icp_final<<<ICP_SLOTS, 64, 0, ctx->stream>>>(d_part, nblocks, d_sum);
         R3D_HIP(ctx, hipGetLastError());

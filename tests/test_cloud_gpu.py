@@ -277,7 +277,7 @@ def test_lds_tiled_search_kernel_matches_default():
         "    r = r3d.cloud_ops.registration(src, tgt, 0.02, mode=mode, max_iteration=6, source_normals=sn, target_normals=tn)\n"
         "    print('RES', mode, r['T'].tobytes().hex(), r['correspondences'], repr(r['inlier_rmse']))\n")
     outs = []
-    for impl in ("exact", "tiled", "default"):
+    for impl in ("exact", "tiled", "default", "f32"):
         env = dict(os.environ, R3D_ICP_IMPL=impl)
         o = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
         lines = [ln.split() for ln in o.stdout.splitlines() if ln.startswith("RES")]
@@ -287,9 +287,11 @@ def test_lds_tiled_search_kernel_matches_default():
         assert a[3] == b[3] and int(a[3]) > 50000                                     # correspondences
         Ta, Tb = (np.frombuffer(bytes.fromhex(x[2])).reshape(4, 4) for x in (a, b))
         assert np.abs(Ta - Tb).max() < 1e-12 and abs(float(a[4]) - float(b[4])) < 1e-12
-    # the default two-stage search (float32 top-4, then exact top-3) finds exactly the correspondences of the all-float64
-    # search and sums them in the same order: bit-identical transforms
+    # the two-stage searches (default: packed 10-bit cell-relative candidates with row pruning; f32: float32 copies of all
+    # nine rows; both followed by the exact evaluation of the best three) find exactly the correspondences of the all-float64
+    # search and sum them in the same order: bit-identical transforms
     assert outs[0] == outs[2]
+    assert outs[0] == outs[3]
 
 
 def test_non_finite_coordinates_are_refused(r3d):
@@ -330,3 +332,43 @@ def test_fused_align_call_equals_chained_entry_points(r3d, mode):
     else:
         with pytest.raises(r3d.R3DError):
             ops.align_point_clouds(sp, tp, 0.02, None, 10, mode, None, 0)             # this mode needs normals
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 17])
+def test_tiny_clouds_stay_finite(r3d, n):
+    """Clouds of one to a few points: every cloud entry point returns finite results.  One correspondence pair (or coincident
+    pairs) gives a zero cross-covariance, whose SVD is U = V = I: point-to-point reduces to the translation between the means;
+    collinear pairs (rank 1) take the smallest rotation; rank-deficient 6x6 systems return the identity update like
+    SolveJacobianSystemAndObtainExtrinsicMatrix."""
+    ops = r3d.cloud_ops
+    p = np.random.default_rng(n).random((n, 3))
+    v = ops.voxel_down_sample(p, 0.5)[0]
+    assert 1 <= len(v) <= n
+    nr = ops.estimate_normals(p, 0.5, 30)
+    assert nr.shape == (n, 3) and np.isfinite(nr).all()
+    shift = np.array([0.001, -0.002, 0.0015])
+    res = ops.registration(p, p + shift, 0.05, mode=0, max_iteration=5)
+    assert np.isfinite(res["T"]).all() and res["correspondences"] == n
+    assert np.abs(res["T"][:3, 3] + res["T"][:3, :3] @ p.mean(0) - (p + shift).mean(0)).max() < 1e-12   # means are mapped onto each other
+    if n == 1:
+        np.testing.assert_allclose(res["T"], np.block([[np.eye(3), shift[:, None]], [np.zeros((1, 3)), np.ones((1, 1))]]), atol=1e-15)
+    for mode in (1, 2):
+        res = ops.registration(p, p + shift, 0.05, mode=mode, max_iteration=5, source_normals=nr, target_normals=nr)
+        assert np.isfinite(res["T"]).all()
+    a = ops.align_point_clouds(p, p + shift, 0.05, 0.1, 5, 0, 0.2, 10)
+    assert np.isfinite(a["T"]).all()
+
+
+def test_degenerate_geometry_stays_finite(r3d):
+    ops = r3d.cloud_ops
+    p = np.zeros((100, 3)); p[:, 0] = np.linspace(0, 1, 100)                      # collinear
+    nr = ops.estimate_normals(p, 0.2, 20)
+    assert np.isfinite(nr).all()
+    for mode in (0, 1, 2):
+        res = ops.registration(p, p + np.array([0.0, 0.001, 0.0]), 0.05, mode=mode, max_iteration=3, source_normals=nr, target_normals=nr)
+        assert np.isfinite(res["T"]).all(), mode
+    res = ops.registration(p, p + np.array([0.0, 0.001, 0.0]), 0.05, mode=0, max_iteration=1)
+    np.testing.assert_allclose(res["T"][:3, :3], np.eye(3), atol=1e-12)          # smallest rotation for rank-1 pairs: none
+    d = np.ones((50, 3))                                                          # all points coincident
+    assert np.isfinite(ops.estimate_normals(d, 0.2, 20)).all()
+    assert np.isfinite(ops.registration(d, d, 0.05, mode=0, max_iteration=3)["T"]).all()

@@ -242,3 +242,12 @@ def test_row_stride_larger_than_width(r3d, synth):
     np.testing.assert_array_equal(got, _oracle(L, R, D, C2_KW))
     with pytest.raises(r3d.R3DError):
         m.compute_device(1, 1, W, H, W - 1, 1)                      # stride < width is refused before any access
+
+
+@pytest.mark.parametrize("W,H,D", [(17, 1, 16), (18, 2, 16), (33, 3, 32), (16, 5, 16), (40, 2, 32)])
+def test_tiny_images_bit_exact(r3d, W, H, D):
+    """Images of one to five rows and a matching range of zero to a few columns (W - D = 1, 2, 1, 0, 8)."""
+    rng = np.random.default_rng(W * H)
+    L = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    R = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    np.testing.assert_array_equal(_gpu(r3d, D, C2_KW).compute(L, R), _oracle(L, R, D, C2_KW))
