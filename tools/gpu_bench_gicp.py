@@ -8,7 +8,10 @@ ctx = r3d.default_context(0)
 src, tgt, T_star = r3d.synth.cloud_pair(1_000_000)
 src, tgt = src.astype(np.float64), tgt.astype(np.float64)
 t0 = time.perf_counter(); sn = co.estimate_normals(src, None, 20); tn = co.estimate_normals(tgt, None, 20); print("normals s", time.perf_counter() - t0)
+want = sys.argv[1:] or ["gicp", "p2plane", "p2p"]
 for mode, name in ((co.GICP, "gicp"), (co.P2PLANE, "p2plane"), (co.P2P, "p2p")):
+    if name not in want:
+        continue
     for rep in range(4):
         res = co.registration(src, tgt, 0.02, mode=mode, max_iteration=20, relative_fitness=-1, relative_rmse=-1, source_normals=sn, target_normals=tn)
         print(name, rep, "loop_ms", round(res["loop_ms"], 3), "per iter", round(res["loop_ms"] / 21, 4), "setup", round(res["setup_ms"], 2), "err", float(np.linalg.norm(res["T"] - T_star)), flush=True)

@@ -17,5 +17,8 @@ for d in sys.argv[1:]:
                 m = re.search(r"\bk_[a-z0-9_]+", name)
                 short = m.group(0) if m else name[:40]
                 acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
-out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+if os.environ.get("PMC_MEDIAN"):   # robust against one-off launches (e.g. the first, unaligned evaluation of a registration loop)
+    out = {k: {c: sorted(v)[len(v) // 2] for c, v in cs.items()} for k, cs in acc.items()}
+else:
+    out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
 print(json.dumps(out, indent=1, sort_keys=True))
