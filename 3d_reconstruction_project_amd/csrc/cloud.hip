@@ -548,22 +548,28 @@ __global__ void __launch_bounds__(256) k_soa_f32(const double *__restrict__ pts,
     fz[i] = in ? (float)pts[ic * 3 + 2] : 0.f;
 }
 
-// Packed form of the two-stage search (the default).  Stage 1 of nn_block_top4 costs three 16-byte gathers per four candidates
-// and walks all nine runs of the 3x3x3 block, every run for as long as its longest lane.  Here
-//  (1) a candidate is ONE dword: its position inside its own cell quantised to 10 bits per axis plus the low two bits of its
-//      cell x index (k_pack_q10), so one 16-byte gather brings four candidates; the query is expressed in the same unit
-//      (cell / 1024) relative to the corner of its 3x3x3 block, where every coordinate is below 3072 and float32 is exact
-//      to 2^-12 units.  Reconstruction error of a candidate: half a unit per axis, so |d_stage1 - d_exact| <= 0.867 units
-//      and the margin (FEQ, "fe" of nn_block_top4) is 1.75 units = cell / 585 -- wide enough to be a bound, narrow enough
-//      that a fourth contender inside it stays a once-in-millions event on real clouds;
-//  (2) runs are visited centre row first, and a row whose slab distance to the query exceeds the current margin threshold
-//      (or the correspondence radius) is skipped: it cannot hold the nearest point, a tie with it, or a contender that the
-//      fallback test would have to count;
-//  (3) every lane keeps its own list of non-empty runs (LDS, column per thread) and walks it in ONE loop, so a wave iterates
-//      max-over-lanes of the per-lane total instead of the sum over runs of the per-run maximum.
-// Stage 2 (exact float64 evaluation of the best three, fallback to nn_block_global on a fourth contender) is unchanged, and
-// so is the result: bit-identical to the all-float64 search (tests/test_cloud_gpu.py).
-constexpr float FEQ = 1.75f;
+// Packed form of the two-stage search (the default).  PMC on the float32 form: 51 M VALU wave-instructions per evaluation
+// at 1 M points (3 300 per 64 queries) against 0.5 M gathers -- the search is bound by the vector ALU, not by memory: 37
+// instructions per candidate (most of them the sorted insertion of (distance, slot) into a quadruple), every one of the nine
+// rows walked by the whole wave for as long as its longest lane.  Here
+//  (1) a candidate is ONE dword: its position inside its own cell quantised to 10 bits per axis, x together with the low two
+//      bits of its cell x index (k_pack_q10): one 16-byte gather brings four candidates, and the query is expressed in the
+//      same unit (cell / 1024) relative to the corner of its 3x3x3 block, where every coordinate is below 4096 and float32
+//      is exact to 2^-11 units;
+//  (2) distance and candidate travel as ONE 32-bit key: the float bits of the squared distance with the low 10 mantissa
+//      bits replaced by the candidate's ordinal in this query's scan, so the sorted insertion into the best four is
+//      v_min + 3 x v_med3 (20 instructions per candidate in all);
+//  (3) the centre row is scanned first; a row whose slab distance to the query exceeds the margin threshold of the best
+//      distance so far (or the correspondence radius) is dropped: it cannot hold the nearest point, a tie with it, or a
+//      contender that the fallback test would have to count; the surviving rows go to a per-lane list (LDS, column per
+//      thread) that is walked in ONE loop, so a wave iterates max-over-lanes of the per-lane total instead of the sum over
+//      rows of the per-row maximum.
+// Error budget of stage 1 in units: reconstruction of a candidate 0.5 per axis (0.867 in distance), the query's float
+// coordinates 2.5e-4, key truncation 2^-13 relative in d^2 (<= 0.22 at the far corner of the block): |d_stage1 - d_exact| <=
+// 1.1, FEQ ("fe" of nn_block_top4) = 2.25 units = cell / 455.  Stage 2 (exact float64 evaluation of the best three, fallback
+// to nn_block_global on a fourth contender within the margin) is unchanged, and so is the result: bit-identical to the
+// all-float64 search (tests/test_cloud_gpu.py).  Queries whose nine rows hold more than 1024 candidates use the fallback.
+constexpr float FEQ = 2.25f;
 
 __global__ void __launch_bounds__(256) k_pack_q10(GridView g, int64_t n, unsigned *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -572,21 +578,23 @@ __global__ void __launch_bounds__(256) k_pack_q10(GridView g, int64_t n, unsigne
     if (i < n) {
         const double u[3] = {(g.pts[i * 3] - g.ox) * g.inv_cell, (g.pts[i * 3 + 1] - g.oy) * g.inv_cell, (g.pts[i * 3 + 2] - g.oz) * g.inv_cell};
         const int dims[3] = {g.nx, g.ny, g.nz};
+        unsigned q[3];
         int c0 = 0;
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             const int c = min(max((int)floor(u[a]), 0), dims[a] - 1);   // the cell the point was sorted into (k_cell_keys)
-            const int q = min(max((int)floor((u[a] - c) * 1024.0), 0), 1023);
-            w |= (unsigned)q << (10 * a);
+            q[a] = (unsigned)min(max((int)floor((u[a] - c) * 1024.0), 0), 1023);
             if (a == 0) c0 = c;
         }
-        w |= (unsigned)(c0 & 3) << 30;
+        w = q[0] | (unsigned)(c0 & 3) << 10 | q[1] << 12 | q[2] << 22;
     }
     out[i] = w;
 }
 
+__device__ __forceinline__ int med3_i32(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
+
 __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, double py, double pz, int cx, int cy, int cz, double r2,
-                                             double &best, int &bi, int *__restrict__ sRun /* [27][ICP_BLOCK] */) {
+                                             double &best, int &bi, int *__restrict__ sRun /* [32][ICP_BLOCK] */) {
     constexpr int B = 256;   // = ICP_BLOCK (declared below)
     const int tid = threadIdx.x;
     const int xa = cx - 1, xb = cx + 1;
@@ -595,7 +603,7 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
     typedef int int4_a4 __attribute__((ext_vector_type(4), aligned(4)));
     typedef unsigned uint4_a4 __attribute__((ext_vector_type(4), aligned(4)));
     constexpr int ORD[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};   // centre row, the four rows sharing a face with it, the four corners
-    int rb[9], re[9];
+    int rb[9], re[9], total = 0;
 #pragma unroll
     for (int q = 0; q < 9; q++) {
         const int r = ORD[q];
@@ -606,77 +614,101 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
         const int b = cs.x, de = x1 + 1 - x0, e = de == 3 ? cs.w : de == 2 ? cs.z : cs.y;
         rb[q] = b;
         re[q] = b + ((e - b) & (ok ? -1 : 0));
+        total += (re[q] - rb[q] + 3) & ~3;
     }
-    int nr = 0;
-#pragma unroll
-    for (int q = 0; q < 9; q++) {
-        if (re[q] > rb[q]) {
-            sRun[(nr * 3) * B + tid] = rb[q];
-            sRun[(nr * 3 + 1) * B + tid] = re[q];
-            sRun[(nr * 3 + 2) * B + tid] = ORD[q];
-            nr++;
-        }
+    if (total > 1024) {                            // the ordinal field of the keys would overflow (very dense cells)
+        nn_block_global(g, px, py, pz, cx, cy, cz, best, bi);
+        return;
     }
     // the query in units of cell / 1024 relative to the block corner (cx-1, cy-1, cz-1): [1024, 2048) on every axis
     const double ux = (px - g.ox) * g.inv_cell, uy = (py - g.oy) * g.inv_cell, uz = (pz - g.oz) * g.inv_cell;
     const float qxc = (float)((ux - (double)(cx - 1)) * 1024.0), qyc = (float)((uy - (double)(cy - 1)) * 1024.0),
                 qzc = (float)((uz - (double)(cz - 1)) * 1024.0);
-    const float qx = qxc - 0.5f;          // candidates are reconstructed at the centre of their quantisation step
-    const int xm1 = cx - 1;
-    const float INF = __builtin_huge_valf();
+    const float qx = qxc - 0.5f;                   // candidates are reconstructed at the centre of their quantisation step
+    const unsigned xsub = (unsigned)(cx - 1) << 10;
+    constexpr int KINF = 0x7f800000;
     auto thr_of = [&](float t) { const float tt = sqrtf(t) * 1.000001f + FEQ; return tt * tt * 1.000001f; };
     const float thr_r = thr_of((float)(r2 * g.inv_cell * g.inv_cell * (1024.0 * 1024.0)) * 1.000001f);
-    float t1 = INF, t2 = INF, t3 = INF, t4 = INF;
-    int i1 = -1, i2 = -1, i3 = -1;
-    int k = 0, j0 = 0, e = 0;
-    float qyr = 0.f, qzr = 0.f;
-    for (;;) {
-        if (j0 >= e) {
-            const float thr = fminf(thr_r, thr_of(t1));
-            while (j0 >= e && k < nr) {
-                const int b_ = sRun[(k * 3) * B + tid], e_ = sRun[(k * 3 + 1) * B + tid], r = sRun[(k * 3 + 2) * B + tid];
-                k++;
-                const int rz = (r * 11) >> 5, ry = r - 3 * rz;
-                const float ylo = 1024.f * (float)ry, zlo = 1024.f * (float)rz;
-                const float sy = fmaxf(0.f, fmaxf(ylo - qyc, qyc - (ylo + 1024.f))), sz = fmaxf(0.f, fmaxf(zlo - qzc, qzc - (zlo + 1024.f)));
-                if (sy * sy + sz * sz <= thr) { j0 = b_; e = e_; qyr = qyc - 0.5f - ylo; qzr = qzc - 0.5f - zlo; }
-            }
-            if (j0 >= e) break;
-        }
+    int k1 = KINF, k2 = KINF, k3 = KINF, k4 = KINF;   // the four smallest keys, ascending
+    int ord = 0;
+    auto scan4 = [&](int j0, int e, float qyr, float qzr) {
         const uint4_a4 W = *(const uint4_a4 *)(g.q10 + j0);
+        const int rem = e - j0;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int j = j0 + u;
             const unsigned w = W[u];
-            const int xi = (int)((((w >> 30) - (unsigned)xm1) & 3u) << 10 | (w & 1023u));
-            const float fdx = (float)xi - qx, fdy = (float)((w >> 10) & 1023u) - qyr, fdz = (float)((w >> 20) & 1023u) - qzr;
-            float f = fdx * fdx + fdy * fdy + fdz * fdz;
-            f = j < e ? f : INF;
-            const bool c3 = f < t3, c2 = f < t2, c1 = f < t1;
-            t4 = c3 ? t3 : fminf(t4, f);
-            i3 = c2 ? i2 : (c3 ? j : i3);
-            t3 = c2 ? t2 : (c3 ? f : t3);
-            i2 = c1 ? i1 : (c2 ? j : i2);
-            t2 = c1 ? t1 : (c2 ? f : t2);
-            i1 = c1 ? j : i1;
-            t1 = c1 ? f : t1;
+            const float fdx = (float)((w - xsub) & 4095u) - qx, fdy = (float)((w >> 12) & 1023u) - qyr, fdz = (float)(w >> 22) - qzr;
+            const float f = __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx));
+            int key = (__float_as_int(f) & ~1023) | (ord + u);
+            key = u < rem ? key : KINF;
+            k4 = med3_i32(k3, k4, key);
+            k3 = med3_i32(k2, k3, key);
+            k2 = med3_i32(k1, k2, key);
+            k1 = min(k1, key);
         }
-        j0 += 4;
+        ord += 4;
+    };
+    // centre row first: it gives the pruning threshold for the other eight
+    for (int j0 = rb[0]; j0 < re[0]; j0 += 4) scan4(j0, re[0], qyc - 1024.5f, qzc - 1024.5f);
+    const float thr = fminf(thr_r, thr_of(__int_as_float(k1 & ~1023)) * 1.0003f);   // (key truncation: the key is below f by < 2^-13)
+    sRun[tid] = rb[0];                             // record 0: the centre row (ordinal 0)
+    sRun[B + tid] = 0;
+    int nr = 1, obase = (re[0] - rb[0] + 3) & ~3;
+#pragma unroll
+    for (int q = 1; q < 9; q++) {
+        const int r = ORD[q], ry = r % 3, rz = r / 3;
+        const float sy = ry == 0 ? qyc - 1024.f : ry == 2 ? 2048.f - qyc : 0.f, sz = rz == 0 ? qzc - 1024.f : rz == 2 ? 2048.f - qzc : 0.f;
+        if (re[q] > rb[q] && sy * sy + sz * sz <= thr) {
+            sRun[(nr * 4) * B + tid] = rb[q];
+            sRun[(nr * 4 + 1) * B + tid] = obase;
+            sRun[(nr * 4 + 2) * B + tid] = re[q];
+            sRun[(nr * 4 + 3) * B + tid] = r;
+            obase += (re[q] - rb[q] + 3) & ~3;
+            nr++;
+        }
     }
-    if (!(t1 < INF)) return;                       // nothing scanned: the caller goes on to the outer shells
-    const float thr2 = thr_of(t1);
-    if (t4 <= thr2) {                              // a fourth contender: the triple may be incomplete
+    {
+        int k = 1, j0 = 0, e = 0;
+        float qyr = 0.f, qzr = 0.f;
+        for (;;) {
+            if (j0 >= e) {
+                if (k >= nr) break;
+                j0 = sRun[(k * 4) * B + tid];
+                e = sRun[(k * 4 + 2) * B + tid];
+                const int r = sRun[(k * 4 + 3) * B + tid];
+                const int rz = (r * 11) >> 5, ry = r - 3 * rz;
+                qyr = qyc - 0.5f - 1024.f * (float)ry;
+                qzr = qzc - 0.5f - 1024.f * (float)rz;
+                k++;
+            }
+            scan4(j0, e, qyr, qzr);
+            j0 += 4;
+        }
+    }
+    if (k1 == KINF) return;                        // nothing scanned: the caller goes on to the outer shells
+    const float t1 = __int_as_float(k1 | 1023);    // upper end of the key's truncation interval
+    const float thr2 = thr_of(t1) * 1.0003f;
+    if (__int_as_float(k4 & ~1023) <= thr2) {      // a fourth contender: the triple may be incomplete
         nn_block_global(g, px, py, pz, cx, cy, cz, best, bi);
         return;
     }
-    const int cand[3] = {i1, i2, i3};
-    const float ct[3] = {t1, t2, t3};
+    // ordinal -> slot: the record with the largest ordinal base not above it
+    const int o[3] = {k1 & 1023, k2 & 1023, k3 & 1023};
+    int jb[3] = {sRun[tid], sRun[tid], sRun[tid]}, ob[3] = {0, 0, 0};
+    for (int k = 1; k < nr; k++) {
+        const int b_ = sRun[(k * 4) * B + tid], o_ = sRun[(k * 4 + 1) * B + tid];
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            if (o[q] >= o_) { jb[q] = b_; ob[q] = o_; }
+    }
+    const int kk[3] = {k1, k2, k3};
 #pragma unroll
     for (int q = 0; q < 3; q++) {
-        const int j = max(cand[q], 0);
+        const bool have = kk[q] != KINF;
+        const int j = have ? jb[q] + (o[q] - ob[q]) : 0;   // slot 0 is a valid address: no branch around the loads
         const double dx = g.pts[(int64_t)j * 3] - px, dy = g.pts[(int64_t)j * 3 + 1] - py, dz = g.pts[(int64_t)j * 3 + 2] - pz;
         const double d2 = dx * dx + dy * dy + dz * dz;
-        if (cand[q] >= 0 && ct[q] <= thr2 && d2 <= best) {
+        if (have && __int_as_float(kk[q] & ~1023) <= thr2 && d2 <= best) {
             if (d2 < best || (bi >= 0 && g.idx[j] < g.idx[bi])) { best = d2; bi = j; }
         }
     }
@@ -783,7 +815,7 @@ __global__ void __launch_bounds__(ICP_BLOCK, 3) k_icp_eval(GridView g, const dou
                                                         const IcpState *__restrict__ st, double max_dist, double eps, double *__restrict__ partial,
                                                         int *__restrict__ corr /* optional [ns] target original index or -1 */) {
     static_assert(ICP_BLOCK == 256, "nn_block_q10 assumes 256 threads");
-    __shared__ int sRun[SEARCH == SEARCH_Q10 ? 27 * ICP_BLOCK : 1];
+    __shared__ int sRun[SEARCH == SEARCH_Q10 ? 36 * ICP_BLOCK : 1];
     if (st->done) return;                        // the loop ended in an earlier launch of this batch (uniform)
     const Rigid T = load_rigid(st);
     double acc[ICP_SLOTS];
