@@ -604,14 +604,17 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
     typedef unsigned uint4_a4 __attribute__((ext_vector_type(4), aligned(4)));
     constexpr int ORD[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};   // centre row, the four rows sharing a face with it, the four corners
     int rb[9], re[9], total = 0;
+    // table index of the run's first cell: the table has at most 2^26 entries (grid_build), so 32-bit arithmetic, two vector
+    // multiplies for all nine rows (the row offsets are wave-uniform); rows outside the grid read entry 0 and are emptied
+    const unsigned base = ((unsigned)(cz - 1) * (unsigned)g.ny + (unsigned)(cy - 1)) * (unsigned)g.nx + (unsigned)x0;
+    const int de = x1 + 1 - x0;
 #pragma unroll
     for (int q = 0; q < 9; q++) {
-        const int r = ORD[q];
-        const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
-        const bool ok = xok && z >= 0 && z < g.nz && y >= 0 && y < g.ny;
-        const int64_t row = ((int64_t)min(max(z, 0), g.nz - 1) * g.ny + min(max(y, 0), g.ny - 1)) * g.nx;
-        const int4_a4 cs = *(const int4_a4 *)(g.cstart + row + x0);
-        const int b = cs.x, de = x1 + 1 - x0, e = de == 3 ? cs.w : de == 2 ? cs.z : cs.y;
+        const int r = ORD[q], rz = r / 3, ry = r % 3;
+        const bool ok = xok && (unsigned)(cz + rz - 1) < (unsigned)g.nz && (unsigned)(cy + ry - 1) < (unsigned)g.ny;
+        const unsigned off = ((unsigned)rz * (unsigned)g.ny + (unsigned)ry) * (unsigned)g.nx;
+        const int4_a4 cs = *(const int4_a4 *)(g.cstart + (ok ? base + off : 0u));
+        const int b = cs.x, e = de == 3 ? cs.w : de == 2 ? cs.z : cs.y;
         rb[q] = b;
         re[q] = b + ((e - b) & (ok ? -1 : 0));
         total += (re[q] - rb[q] + 3) & ~3;
@@ -714,7 +717,12 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
     }
 }
 
-// shells 2.. of the search (only queries whose nearest point is further than one cell away get here)
+// shells 2.. of the search (only queries whose nearest point is further than one cell away get here: most of them in the
+// first evaluation of an unaligned pair, a handful per million afterwards).  A shell is walked by x-rows: a row on a face of
+// the shell is ONE contiguous run of the sorted point array (two table entries instead of 2 (2s+1)), trimmed in x to the
+// cells that can still hold a point nearer than the best so far; a row inside the shell only contributes its two end cells;
+// rows and cells whose nearest face is further than the best distance are skipped (strictly further: ties are still seen, and
+// the result does not depend on the visiting order because of the total order (d2, index)).
 __device__ __forceinline__ void nn_outer_shells(const GridView &g, double px, double py, double pz, int cx, int cy, int cz, int smax,
                                                 double &best, int &bi) {
     auto visit = [&](int b, int e) {
@@ -726,8 +734,47 @@ __device__ __forceinline__ void nn_outer_shells(const GridView &g, double px, do
             }
         }
     };
+    // distance from the query coordinate q to the slab of cell c along one axis (0 inside); SLK shrinks the bound by more
+    // than the rounding of the cell faces, so a point at exactly the best distance is never pruned
+    constexpr double SLK = 1.0 - 1e-9;
+    auto slab = [&](double q, double o, int c) {
+        const double lo = o + (double)c * g.cell, hi = lo + g.cell;
+        return q < lo ? lo - q : (q > hi ? q - hi : 0.0);
+    };
     for (int s = 1; s <= max(smax, 1); s++) {
-        if (s > 1) for_shell(g, cx, cy, cz, s, visit);
+        if (s > 1) {
+            for (int dz = -s; dz <= s; dz++) {
+                const int z = cz + dz;
+                if (z < 0 || z >= g.nz) continue;
+                const double sz = slab(pz, g.oz, z);
+                if (sz * sz * SLK > best) continue;
+                for (int dy = -s; dy <= s; dy++) {
+                    const int y = cy + dy;
+                    if (y < 0 || y >= g.ny) continue;
+                    const double sy = slab(py, g.oy, y), syz = sy * sy + sz * sz;
+                    if (syz * SLK > best) continue;
+                    const int64_t row = ((int64_t)z * g.ny + y) * g.nx;
+                    if (dz == -s || dz == s || dy == -s || dy == s) {
+                        // cells further than kx from the query's cell lie at least kx * cell away in x
+                        const int kx = min(s, (int)(sqrt(fmax(best - syz * SLK, 0.0)) * g.inv_cell) + 1);
+                        const int x0 = max(cx - kx, 0), x1 = min(cx + kx, g.nx - 1);
+                        if (x0 > x1) continue;
+                        const int b = g.cstart[row + x0], e = g.cstart[row + x1 + 1];
+                        visit(b, e);
+                    } else {
+#pragma unroll
+                        for (int side = 0; side < 2; side++) {
+                            const int x = side ? cx + s : cx - s;
+                            if (x < 0 || x >= g.nx) continue;
+                            const double sx = slab(px, g.ox, x);
+                            if ((sx * sx + syz) * SLK > best) continue;
+                            const int b = g.cstart[row + x], e = g.cstart[row + x + 1];
+                            visit(b, e);
+                        }
+                    }
+                }
+            }
+        }
         const double reach = s * g.cell;
         if (bi >= 0 && best <= reach * reach) break;
     }
@@ -1493,7 +1540,12 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
     // the gathers they replace once the source is Morton-ordered)
     const char *impl_env = getenv("R3D_ICP_IMPL");
     const bool tiled_impl = impl_env && strcmp(impl_env, "tiled") == 0;
-    const int nblocks = tiled_impl ? (int)std::min<int64_t>((ns + 63) / 64, 8192) : (int)std::min<int64_t>((ns + ICP_BLOCK - 1) / ICP_BLOCK, 2048);
+    // one residency of the chip (3 workgroups per CU at the kernel's register count): every wave starts at once, walks its share
+    // of the queries in a grid-stride loop and pays the 29-slot reduction once
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const int nblocks = tiled_impl ? (int)std::min<int64_t>((ns + 63) / 64, 8192)
+                                   : (int)std::min<int64_t>((ns + ICP_BLOCK - 1) / ICP_BLOCK, (int64_t)std::max(cus, 1) * 3);
     double *d_part = (double *)ar.get((size_t)nblocks * ICP_SLOTS * 8);
     IcpState *d_st = (IcpState *)ar.get(sizeof(IcpState));
     if (ar.rc) return ar.rc;
