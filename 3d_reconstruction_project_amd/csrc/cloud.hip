@@ -603,7 +603,7 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
     typedef int int4_a4 __attribute__((ext_vector_type(4), aligned(4)));
     typedef unsigned uint4_a4 __attribute__((ext_vector_type(4), aligned(4)));
     constexpr int ORD[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};   // centre row, the four rows sharing a face with it, the four corners
-    int rb[9], re[9], total = 0;
+    int rb[9], re[9], rm1[9], rm2[9], total = 0;   // run bounds and the two cell boundaries inside a full three-cell run
     // table index of the run's first cell: the table has at most 2^26 entries (grid_build), so 32-bit arithmetic, two vector
     // multiplies for all nine rows (the row offsets are wave-uniform); rows outside the grid read entry 0 and are emptied
     const unsigned base = ((unsigned)(cz - 1) * (unsigned)g.ny + (unsigned)(cy - 1)) * (unsigned)g.nx + (unsigned)x0;
@@ -617,6 +617,8 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
         const int b = cs.x, e = de == 3 ? cs.w : de == 2 ? cs.z : cs.y;
         rb[q] = b;
         re[q] = b + ((e - b) & (ok ? -1 : 0));
+        rm1[q] = cs.y;
+        rm2[q] = cs.z;
         total += (re[q] - rb[q] + 3) & ~3;
     }
     if (total > 1024) {                            // the ordinal field of the keys would overflow (very dense cells)
@@ -654,6 +656,8 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
     // centre row first: it gives the pruning threshold for the other eight
     for (int j0 = rb[0]; j0 < re[0]; j0 += 4) scan4(j0, re[0], qyc - 1024.5f, qzc - 1024.5f);
     const float thr = fminf(thr_r, thr_of(__int_as_float(k1 & ~1023)) * 1.0003f);   // (key truncation: the key is below f by < 2^-13)
+    const bool trim = de == 3 && xa == x0;         // the run is exactly the cells cx-1, cx, cx+1 (no clamping at the grid border)
+    const float sxl = (qxc - 1024.f) * (qxc - 1024.f), sxh = (2048.f - qxc) * (2048.f - qxc);
     sRun[tid] = rb[0];                             // record 0: the centre row (ordinal 0)
     sRun[B + tid] = 0;
     int nr = 1, obase = (re[0] - rb[0] + 3) & ~3;
@@ -661,12 +665,15 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
     for (int q = 1; q < 9; q++) {
         const int r = ORD[q], ry = r % 3, rz = r / 3;
         const float sy = ry == 0 ? qyc - 1024.f : ry == 2 ? 2048.f - qyc : 0.f, sz = rz == 0 ? qzc - 1024.f : rz == 2 ? 2048.f - qzc : 0.f;
-        if (re[q] > rb[q] && sy * sy + sz * sz <= thr) {
-            sRun[(nr * 4) * B + tid] = rb[q];
+        const float syz = sy * sy + sz * sz;
+        // a full run (cells cx-1, cx, cx+1) also drops an end cell that is too far in x
+        const int b_ = trim && sxl + syz > thr ? rm1[q] : rb[q], e_ = trim && sxh + syz > thr ? rm2[q] : re[q];
+        if (e_ > b_ && syz <= thr) {
+            sRun[(nr * 4) * B + tid] = b_;
             sRun[(nr * 4 + 1) * B + tid] = obase;
-            sRun[(nr * 4 + 2) * B + tid] = re[q];
+            sRun[(nr * 4 + 2) * B + tid] = e_;
             sRun[(nr * 4 + 3) * B + tid] = r;
-            obase += (re[q] - rb[q] + 3) & ~3;
+            obase += (e_ - b_ + 3) & ~3;
             nr++;
         }
     }
@@ -1477,7 +1484,9 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
                     std::chrono::steady_clock::time_point t_begin) {
     int rc;
     Grid G;
-    if ((rc = grid_build(ctx, ar, d_t, nt, p->max_correspondence_distance, 3.0, G))) return rc;
+    double occ = 3.0;   // points per occupied cell the search grid aims at (R3D_ICP_OCC: A/B)
+    if (const char *oe = getenv("R3D_ICP_OCC")) { const double v = atof(oe); if (v >= 0.5 && v <= 64) occ = v; }
+    if ((rc = grid_build(ctx, ar, d_t, nt, p->max_correspondence_distance, occ, G))) return rc;
     // float32 copy for the two-stage search (R3D_ICP_IMPL=exact: all-float64 search, for A/B).  fe = 2 x bound on
     // |float distance - exact distance|: both end points are rounded to float (relative 2^-24 per coordinate), times a
     // safety factor of 2; skipped (exact search) when the coordinates are so large that the margin stops filtering.

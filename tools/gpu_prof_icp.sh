@@ -12,6 +12,7 @@ for impl in ${IMPLS:-default f32}; do
   export R3D_ICP_IMPL=$impl
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${tag}_${impl}_kt -o k -- python3 tools/gpu_bench_gicp.py gicp > "$out/${tag}_${impl}_kt.log" 2>&1
   cp /tmp/prof_${tag}_${impl}_kt/k_kernel_stats.csv "$out/${tag}_${impl}_kernel_stats.csv"
+  python3 tools/trace_gaps.py /tmp/prof_${tag}_${impl}_kt/k_kernel_trace.csv > "$out/${tag}_${impl}_gaps.json"
   rocprofv3 --pmc $A --output-format csv -d /tmp/prof_${tag}_${impl}_a -o p -- python3 tools/gpu_bench_gicp.py gicp > /dev/null 2>&1
   rocprofv3 --pmc $B --output-format csv -d /tmp/prof_${tag}_${impl}_b -o p -- python3 tools/gpu_bench_gicp.py gicp > /dev/null 2>&1
   PMC_MEDIAN=1 python3 tools/pmc_summary.py /tmp/prof_${tag}_${impl}_a /tmp/prof_${tag}_${impl}_b > "$out/${tag}_${impl}_pmc.json"
