@@ -668,7 +668,7 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
         const float syz = sy * sy + sz * sz;
         // a full run (cells cx-1, cx, cx+1) also drops an end cell that is too far in x
         const int b_ = trim && sxl + syz > thr ? rm1[q] : rb[q], e_ = trim && sxh + syz > thr ? rm2[q] : re[q];
-        if (e_ > b_ && syz <= thr) {
+        if (re[q] > rb[q] && e_ > b_ && syz <= thr) {   // (a row outside the grid has re == rb and meaningless cell boundaries)
             sRun[(nr * 4) * B + tid] = b_;
             sRun[(nr * 4 + 1) * B + tid] = obase;
             sRun[(nr * 4 + 2) * B + tid] = e_;

@@ -275,16 +275,24 @@ def test_lds_tiled_search_kernel_matches_default():
         "sn, tn = r3d.cloud_ops.estimate_normals(src, None, 20), r3d.cloud_ops.estimate_normals(tgt, None, 20)\n"
         "for mode in (0, 1, 2):\n"
         "    r = r3d.cloud_ops.registration(src, tgt, 0.02, mode=mode, max_iteration=6, source_normals=sn, target_normals=tn)\n"
-        "    print('RES', mode, r['T'].tobytes().hex(), r['correspondences'], repr(r['inlier_rmse']))\n")
+        "    print('RES', mode, r['T'].tobytes().hex(), r['correspondences'], repr(r['inlier_rmse']))\n"
+        # a thin slab whose source overhangs the target on every side: queries in border cells and outside the grid
+        "rng = np.random.default_rng(5)\n"
+        "tgt = np.c_[rng.random((40000, 2)), 0.002 * rng.standard_normal(40000)]\n"
+        "src = np.c_[rng.random((30000, 2)) * 1.1 - 0.05, 0.002 * rng.standard_normal(30000)] + np.array([0.004, -0.003, 0.002])\n"
+        "sn, tn = r3d.cloud_ops.estimate_normals(src, None, 20), r3d.cloud_ops.estimate_normals(tgt, None, 20)\n"
+        "for mode in (0, 1, 2):\n"
+        "    r = r3d.cloud_ops.registration(src, tgt, 0.02, mode=mode, max_iteration=6, source_normals=sn, target_normals=tn)\n"
+        "    print('RES', 3 + mode, r['T'].tobytes().hex(), r['correspondences'], repr(r['inlier_rmse']))\n")
     outs = []
     for impl in ("exact", "tiled", "default", "f32"):
         env = dict(os.environ, R3D_ICP_IMPL=impl)
         o = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
         lines = [ln.split() for ln in o.stdout.splitlines() if ln.startswith("RES")]
-        assert len(lines) == 3, o.stdout + o.stderr
+        assert len(lines) == 6, o.stdout + o.stderr
         outs.append(lines)
     for a, b in zip(outs[0], outs[1]):
-        assert a[3] == b[3] and int(a[3]) > 50000                                     # correspondences
+        assert a[3] == b[3] and int(a[3]) > 20000                                     # correspondences
         Ta, Tb = (np.frombuffer(bytes.fromhex(x[2])).reshape(4, 4) for x in (a, b))
         assert np.abs(Ta - Tb).max() < 1e-12 and abs(float(a[4]) - float(b[4])) < 1e-12
     # the two-stage searches (default: packed 10-bit cell-relative candidates with row pruning; f32: float32 copies of all
