@@ -877,7 +877,20 @@ __global__ void __launch_bounds__(ICP_BLOCK, 3) k_icp_eval(GridView g, const dou
     for (int q = 0; q < ICP_SLOTS; q++) acc[q] = 0;
     const double r2 = max_dist * max_dist;
     const int smax = (int)ceil(max_dist * g.inv_cell);
-    for (int64_t i = (int64_t)blockIdx.x * ICP_BLOCK + threadIdx.x; i < ns; i += (int64_t)gridDim.x * ICP_BLOCK) {
+    // XCD-aware share of the queries: workgroups go round-robin to the eight XCDs, each with an L2 of its own; the source is in
+    // Morton order of the target cells, so giving XCD x the x-th eighth of the chunks (256 consecutive queries) confines the
+    // target data an L2 sees (cell table, packed candidates, points, normals) to an eighth of the cloud
+    const int64_t nchunk = (ns + ICP_BLOCK - 1) / ICP_BLOCK;
+    int64_t c_begin = blockIdx.x, c_end = nchunk, c_step = gridDim.x;
+    if ((gridDim.x & 7) == 0) {
+        const int x = blockIdx.x & 7;
+        c_begin = x * nchunk / 8 + (blockIdx.x >> 3);
+        c_end = (x + 1) * nchunk / 8;
+        c_step = gridDim.x >> 3;
+    }
+    for (int64_t c = c_begin; c < c_end; c += c_step) {
+        const int64_t i = c * ICP_BLOCK + threadIdx.x;
+        if (i >= ns) continue;
         const double sx = src[i * 3], sy = src[i * 3 + 1], sz = src[i * 3 + 2];
         const double px = T.r[0] * sx + T.r[1] * sy + T.r[2] * sz + T.t[0];
         const double py = T.r[3] * sx + T.r[4] * sy + T.r[5] * sz + T.t[1];
