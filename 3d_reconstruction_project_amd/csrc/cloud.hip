@@ -1479,7 +1479,9 @@ int normals_core(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, doubl
     Grid G;
     const int k = (int)std::min<int64_t>(max_nn, n);
     int rc;
-    if ((rc = grid_build(ctx, ar, d_p, n, radius, std::max(2.0, k / 5.0), G))) return rc;
+    double occ = std::max(2.0, k / 5.0);
+    if (const char *oe = getenv("R3D_KNN_OCC")) { const double v = atof(oe); if (v >= 0.5 && v <= 256) occ = v; }
+    if ((rc = grid_build(ctx, ar, d_p, n, radius, occ, G))) return rc;
     double *d_n = (double *)ar.get((size_t)n * 24);
     if (ar.rc) return ar.rc;
     const size_t lds = (size_t)k * KNN_BLOCK * 12;
