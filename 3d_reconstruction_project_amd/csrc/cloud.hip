@@ -1225,18 +1225,23 @@ __host__ __device__ void mat4_mul(const double A[16], const double B[16], double
 // registration iteration (this, umeyama_from_sums, solve6_to_matrix) runs in one thread of k_icp_step.
 __host__ __device__ void jacobi_eig3(double A[3][3], double V[3][3]) {
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) V[i][j] = i == j;
+    // Cyclic Jacobi with the annihilated element set to exactly zero: the off-diagonal mass then falls quadratically to below
+    // 1e-30 of the diagonal in 5-7 sweeps.  (Without the explicit zero the rounding residue of every rotation, ~1e-17 of the
+    // diagonal, keeps all 60 sweeps busy: 72 us per step in one GPU thread, three times the evaluation kernel of a 40 k-point
+    // cloud.)
     for (int sweep = 0; sweep < 60; sweep++) {
-        double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
-        if (off < 1e-300) break;
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]), scale = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
+        if (off < 1e-300 || off <= 1e-30 * scale) break;
         for (int p = 0; p < 2; p++)
             for (int q = p + 1; q < 3; q++) {
-                if (fabs(A[p][q]) < 1e-300) continue;
+                if (fabs(A[p][q]) <= 1e-33 * scale) { A[p][q] = A[q][p] = 0; continue; }
                 double theta = (A[q][q] - A[p][p]) / (2 * A[p][q]);
                 double t = (theta >= 0 ? 1 : -1) / (fabs(theta) + sqrt(theta * theta + 1));
                 double c = 1 / sqrt(t * t + 1), s = t * c;
                 for (int k = 0; k < 3; k++) { double a = A[k][p], b = A[k][q]; A[k][p] = c * a - s * b; A[k][q] = s * a + c * b; }
                 for (int k = 0; k < 3; k++) { double a = A[p][k], b = A[q][k]; A[p][k] = c * a - s * b; A[q][k] = s * a + c * b; }
                 for (int k = 0; k < 3; k++) { double a = V[k][p], b = V[k][q]; V[k][p] = c * a - s * b; V[k][q] = s * a + c * b; }
+                A[p][q] = A[q][p] = 0;
             }
     }
 }
