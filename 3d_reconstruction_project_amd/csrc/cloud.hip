@@ -183,6 +183,54 @@ __device__ __forceinline__ void for_block3(const GridView &g, int cx, int cy, in
     }
 }
 
+// Shell s >= 2 walked by x-rows with pruning.  A row on a face of the shell is ONE contiguous run of the sorted point array
+// (two table entries instead of 2 (2s+1)), trimmed in x to the cells that can still hold a useful point; a row inside the
+// shell only contributes its two end cells; rows and cells whose nearest face is further than bound() are skipped.
+// bound() is the squared distance beyond which a candidate is useless to the caller (re-read for every row, so it tightens
+// as the caller's result improves); the comparison is strict and shrunk by more than the rounding of the cell faces, so a
+// point at exactly the bound is still visited (ties are decided by the caller's total order).
+template <class Bound, class F>
+__device__ __forceinline__ void for_shell_rows(const GridView &g, double px, double py, double pz, int cx, int cy, int cz, int s,
+                                               Bound &&bound, F &&visit) {
+    constexpr double SLK = 1.0 - 1e-9;
+    auto slab = [&](double q, double o, int c) {   // distance from coordinate q to the slab of cell c along one axis (0 inside)
+        const double lo = o + (double)c * g.cell, hi = lo + g.cell;
+        return q < lo ? lo - q : (q > hi ? q - hi : 0.0);
+    };
+    for (int dz = -s; dz <= s; dz++) {
+        const int z = cz + dz;
+        if (z < 0 || z >= g.nz) continue;
+        const double sz = slab(pz, g.oz, z);
+        if (sz * sz * SLK > bound()) continue;
+        for (int dy = -s; dy <= s; dy++) {
+            const int y = cy + dy;
+            if (y < 0 || y >= g.ny) continue;
+            const double sy = slab(py, g.oy, y), syz = sy * sy + sz * sz, bnd = bound();
+            if (syz * SLK > bnd) continue;
+            const int64_t row = ((int64_t)z * g.ny + y) * g.nx;
+            if (dz == -s || dz == s || dy == -s || dy == s) {
+                // cells further than kx from the query's cell lie at least (kx - 1) * cell away in x
+                const double rx = sqrt(fmax(bnd - syz * SLK, 0.0)) * g.inv_cell;
+                const int kx = rx < (double)s ? (int)rx + 1 : s;
+                const int x0 = max(cx - min(kx, s), 0), x1 = min(cx + min(kx, s), g.nx - 1);
+                if (x0 > x1) continue;
+                const int b = g.cstart[row + x0], e = g.cstart[row + x1 + 1];
+                if (e > b) visit(b, e);
+            } else {
+#pragma unroll
+                for (int side = 0; side < 2; side++) {
+                    const int x = side ? cx + s : cx - s;
+                    if (x < 0 || x >= g.nx) continue;
+                    const double sx = slab(px, g.ox, x);
+                    if ((sx * sx + syz) * SLK > bound()) continue;
+                    const int b = g.cstart[row + x], e = g.cstart[row + x + 1];
+                    if (e > b) visit(b, e);
+                }
+            }
+        }
+    }
+}
+
 // max shells needed to cover the whole grid from a clamped centre
 __device__ __forceinline__ int max_shell(const GridView &g, int cx, int cy, int cz) {
     int m = max(max(cx, g.nx - 1 - cx), max(max(cy, g.ny - 1 - cy), max(cz, g.nz - 1 - cz)));
@@ -225,7 +273,8 @@ __device__ __forceinline__ int knn_query(const GridView &g, double qx, double qy
     };
     for (int s = 1; s <= smax; s++) {
         if (s == 1) for_block3(g, cx, cy, cz, visit);      // shells 0 and 1 as nine contiguous runs
-        else for_shell(g, cx, cy, cz, s, visit);
+        else for_shell_rows(g, qx, qy, qz, cx, cy, cz, s,
+                            [&]() { return cnt == k ? fmin(sd[(k - 1) * KNN_BLOCK + t], r2) : r2; }, visit);
         // everything not visited yet is at least s*cell away
         const double reach = s * g.cell;
         if (radius > 0 && reach >= radius) break;
@@ -238,13 +287,15 @@ __device__ __forceinline__ int knn_query(const GridView &g, double qx, double qy
 __device__ __forceinline__ void smallest_eigvec(double a00, double a01, double a02, double a11, double a12, double a22, double n[3]) {
     double A[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
     double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    // the annihilated element is set to exactly zero and the stop is relative: 4-6 sweeps (an absolute 1e-300 is never
+    // reached because of the rounding residue of each rotation, so all 12 sweeps used to run)
     for (int sweep = 0; sweep < 12; sweep++) {
-        double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
-        if (off < 1e-300) break;
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]), scale = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
+        if (off < 1e-300 || off <= 1e-30 * scale) break;
 #pragma unroll
         for (int pq = 0; pq < 3; pq++) {
             const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
-            if (fabs(A[p][q]) < 1e-300) continue;
+            if (fabs(A[p][q]) <= 1e-33 * scale) { A[p][q] = A[q][p] = 0; continue; }
             double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
             double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
             double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
@@ -266,6 +317,7 @@ __device__ __forceinline__ void smallest_eigvec(double a00, double a01, double a
                 V[k][p] = c * vkp - s * vkq;
                 V[k][q] = s * vkp + c * vkq;
             }
+            A[p][q] = A[q][p] = 0;
         }
     }
     // static selects only (a runtime column index would push V to scratch memory)
@@ -724,12 +776,9 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
     }
 }
 
-// shells 2.. of the search (only queries whose nearest point is further than one cell away get here: most of them in the
-// first evaluation of an unaligned pair, a handful per million afterwards).  A shell is walked by x-rows: a row on a face of
-// the shell is ONE contiguous run of the sorted point array (two table entries instead of 2 (2s+1)), trimmed in x to the
-// cells that can still hold a point nearer than the best so far; a row inside the shell only contributes its two end cells;
-// rows and cells whose nearest face is further than the best distance are skipped (strictly further: ties are still seen, and
-// the result does not depend on the visiting order because of the total order (d2, index)).
+// shells 2.. of the 1-NN search (only queries whose nearest point is further than one cell away get here: most of them in the
+// first evaluation of an unaligned pair, a handful per million afterwards), by pruned x-rows (for_shell_rows); the result does
+// not depend on the visiting order because of the total order (d2, index).
 __device__ __forceinline__ void nn_outer_shells(const GridView &g, double px, double py, double pz, int cx, int cy, int cz, int smax,
                                                 double &best, int &bi) {
     auto visit = [&](int b, int e) {
@@ -741,47 +790,8 @@ __device__ __forceinline__ void nn_outer_shells(const GridView &g, double px, do
             }
         }
     };
-    // distance from the query coordinate q to the slab of cell c along one axis (0 inside); SLK shrinks the bound by more
-    // than the rounding of the cell faces, so a point at exactly the best distance is never pruned
-    constexpr double SLK = 1.0 - 1e-9;
-    auto slab = [&](double q, double o, int c) {
-        const double lo = o + (double)c * g.cell, hi = lo + g.cell;
-        return q < lo ? lo - q : (q > hi ? q - hi : 0.0);
-    };
     for (int s = 1; s <= max(smax, 1); s++) {
-        if (s > 1) {
-            for (int dz = -s; dz <= s; dz++) {
-                const int z = cz + dz;
-                if (z < 0 || z >= g.nz) continue;
-                const double sz = slab(pz, g.oz, z);
-                if (sz * sz * SLK > best) continue;
-                for (int dy = -s; dy <= s; dy++) {
-                    const int y = cy + dy;
-                    if (y < 0 || y >= g.ny) continue;
-                    const double sy = slab(py, g.oy, y), syz = sy * sy + sz * sz;
-                    if (syz * SLK > best) continue;
-                    const int64_t row = ((int64_t)z * g.ny + y) * g.nx;
-                    if (dz == -s || dz == s || dy == -s || dy == s) {
-                        // cells further than kx from the query's cell lie at least kx * cell away in x
-                        const int kx = min(s, (int)(sqrt(fmax(best - syz * SLK, 0.0)) * g.inv_cell) + 1);
-                        const int x0 = max(cx - kx, 0), x1 = min(cx + kx, g.nx - 1);
-                        if (x0 > x1) continue;
-                        const int b = g.cstart[row + x0], e = g.cstart[row + x1 + 1];
-                        visit(b, e);
-                    } else {
-#pragma unroll
-                        for (int side = 0; side < 2; side++) {
-                            const int x = side ? cx + s : cx - s;
-                            if (x < 0 || x >= g.nx) continue;
-                            const double sx = slab(px, g.ox, x);
-                            if ((sx * sx + syz) * SLK > best) continue;
-                            const int b = g.cstart[row + x], e = g.cstart[row + x + 1];
-                            visit(b, e);
-                        }
-                    }
-                }
-            }
-        }
+        if (s > 1) for_shell_rows(g, px, py, pz, cx, cy, cz, s, [&]() { return best; }, visit);
         const double reach = s * g.cell;
         if (bi >= 0 && best <= reach * reach) break;
     }
