@@ -238,6 +238,12 @@ __device__ __forceinline__ int max_shell(const GridView &g, int cx, int cy, int 
 }
 
 // ---- k nearest (<= k, distance < radius if radius > 0), sorted ascending, in LDS columns [slot][thread]
+// Selection is "replace the maximum": the list stays UNSORTED while candidates stream by, its largest element (in the total
+// order (d2, original index)) and that element's slot live in registers; an accepted candidate overwrites the maximum and
+// the maximum is found again by one branch-free pass over the k slots.  A sorted insertion costs every lane of the wave the
+// longest shift chain of any lane at every candidate (PMC: 71 k instructions per 64 queries, 53 % of them scalar loop
+// control); here a wave pays one fixed k-slot pass when any of its lanes accepts.  The list is sorted once at the end, so
+// callers see the same ascending order (and the same summation order) as before.
 constexpr int KNN_BLOCK = 64;
 template <bool unused = true>
 __device__ __forceinline__ int knn_query(const GridView &g, double qx, double qy, double qz, int k, double radius,
@@ -245,40 +251,78 @@ __device__ __forceinline__ int knn_query(const GridView &g, double qx, double qy
     const int t = threadIdx.x;
     const double r2 = radius > 0 ? radius * radius : 1e300;
     int cnt = 0;
+    double maxd = 0.0;      // valid when cnt == k: the list's largest (d2, index) and its slot
+    int maxpos = 0, maxslot = 0;
     const int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
     const int smax = max_shell(g, min(max(cx, 0), g.nx - 1), min(max(cy, 0), g.ny - 1), min(max(cz, 0), g.nz - 1)) + 1;
+    // total order (d2, original index): exact-distance ties are common on voxelised / fp32-rounded clouds, and the oracle
+    // breaks them the same way; the index loads stay off the hot path (only on an exact tie)
+    auto find_max = [&]() {
+        double m = sd[t];
+        int mp = 0, ms = si[t];
+        for (int j = 1; j < k; j++) {
+            const double v = sd[j * KNN_BLOCK + t];
+            const int vs = si[j * KNN_BLOCK + t];
+            bool gt = v > m;
+            if (v == m) gt = g.idx[vs] > g.idx[ms];
+            m = gt ? v : m; mp = gt ? j : mp; ms = gt ? vs : ms;
+        }
+        maxd = m; maxpos = mp; maxslot = ms;
+    };
+    // candidates are fetched four at a time from clamped slots (no branch around a load)
     auto visit = [&](int b, int e) {
-        for (int i = b; i < e; i++) {
-            double dx = g.pts[(int64_t)i * 3] - qx, dy = g.pts[(int64_t)i * 3 + 1] - qy, dz = g.pts[(int64_t)i * 3 + 2] - qz;
-            double d2 = dx * dx + dy * dy + dz * dz;
-            if (!(d2 < r2)) continue;
-            // total order (d2, original index): exact-distance ties are common on voxelised / fp32-rounded clouds,
-            // and the oracle breaks them the same way
-            if (cnt == k) {
-                const double worst = sd[(k - 1) * KNN_BLOCK + t];
-                if (d2 > worst || (d2 == worst && g.idx[i] > g.idx[si[(k - 1) * KNN_BLOCK + t]])) continue;
+        for (int i0 = b; i0 < e; i0 += 4) {
+            double X[4], Y[4], Z[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int64_t ii = min(i0 + u, e - 1);
+                X[u] = g.pts[ii * 3]; Y[u] = g.pts[ii * 3 + 1]; Z[u] = g.pts[ii * 3 + 2];
             }
-            int pos = cnt < k ? cnt : k - 1;
-            while (pos > 0) {
-                const double pd = sd[(pos - 1) * KNN_BLOCK + t];
-                if (!(pd > d2 || (pd == d2 && g.idx[si[(pos - 1) * KNN_BLOCK + t]] > g.idx[i]))) break;
-                sd[pos * KNN_BLOCK + t] = pd;
-                si[pos * KNN_BLOCK + t] = si[(pos - 1) * KNN_BLOCK + t];
-                pos--;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u;
+                if (i >= e) break;
+                const double dx = X[u] - qx, dy = Y[u] - qy, dz = Z[u] - qz;
+                const double d2 = dx * dx + dy * dy + dz * dz;
+                if (!(d2 < r2)) continue;
+                if (cnt < k) {
+                    sd[cnt * KNN_BLOCK + t] = d2;
+                    si[cnt * KNN_BLOCK + t] = i;
+                    if (++cnt == k) find_max();
+                } else {
+                    bool acc = d2 < maxd;
+                    if (d2 == maxd) acc = g.idx[i] < g.idx[maxslot];
+                    if (acc) {
+                        sd[maxpos * KNN_BLOCK + t] = d2;
+                        si[maxpos * KNN_BLOCK + t] = i;
+                        find_max();
+                    }
+                }
             }
-            sd[pos * KNN_BLOCK + t] = d2;
-            si[pos * KNN_BLOCK + t] = i;
-            if (cnt < k) cnt++;
         }
     };
     for (int s = 1; s <= smax; s++) {
         if (s == 1) for_block3(g, cx, cy, cz, visit);      // shells 0 and 1 as nine contiguous runs
-        else for_shell_rows(g, qx, qy, qz, cx, cy, cz, s,
-                            [&]() { return cnt == k ? fmin(sd[(k - 1) * KNN_BLOCK + t], r2) : r2; }, visit);
+        else for_shell_rows(g, qx, qy, qz, cx, cy, cz, s, [&]() { return cnt == k ? fmin(maxd, r2) : r2; }, visit);
         // everything not visited yet is at least s*cell away
         const double reach = s * g.cell;
         if (radius > 0 && reach >= radius) break;
-        if (cnt == k && sd[(k - 1) * KNN_BLOCK + t] <= reach * reach) break;
+        if (cnt == k && maxd <= reach * reach) break;
+    }
+    // ascending (d2, index): insertion sort of the final list, once per query
+    for (int a = 1; a < cnt; a++) {
+        const double d2 = sd[a * KNN_BLOCK + t];
+        const int i = si[a * KNN_BLOCK + t];
+        int pos = a;
+        while (pos > 0) {
+            const double pd = sd[(pos - 1) * KNN_BLOCK + t];
+            if (!(pd > d2 || (pd == d2 && g.idx[si[(pos - 1) * KNN_BLOCK + t]] > g.idx[i]))) break;
+            sd[pos * KNN_BLOCK + t] = pd;
+            si[pos * KNN_BLOCK + t] = si[(pos - 1) * KNN_BLOCK + t];
+            pos--;
+        }
+        sd[pos * KNN_BLOCK + t] = d2;
+        si[pos * KNN_BLOCK + t] = i;
     }
     return cnt;
 }
@@ -346,11 +390,20 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_normals(GridView g, int64_t n, in
     double nrm[3] = {0.0, 0.0, 1.0};
     if (cnt >= 3) {
         double sx = 0, sy = 0, sz = 0, xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
-        for (int j = 0; j < cnt; j++) {
-            const int64_t s = si[j * KNN_BLOCK + t];
-            const double x = g.pts[s * 3] - qx, y = g.pts[s * 3 + 1] - qy, z = g.pts[s * 3 + 2] - qz;  // centred on the query
-            sx += x; sy += y; sz += z;
-            xx += x * x; xy += x * y; xz += x * z; yy += y * y; yz += y * z; zz += z * z;
+        for (int j0 = 0; j0 < cnt; j0 += 4) {       // four neighbours per round trip, summed in list order as before
+            double X[4], Y[4], Z[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int64_t s = si[min(j0 + u, cnt - 1) * KNN_BLOCK + t];
+                X[u] = g.pts[s * 3]; Y[u] = g.pts[s * 3 + 1]; Z[u] = g.pts[s * 3 + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (j0 + u >= cnt) break;
+                const double x = X[u] - qx, y = Y[u] - qy, z = Z[u] - qz;  // centred on the query
+                sx += x; sy += y; sz += z;
+                xx += x * x; xy += x * y; xz += x * z; yy += y * y; yz += y * z; zz += z * z;
+            }
         }
         const double inv = 1.0 / cnt;
         sx *= inv; sy *= inv; sz *= inv;
