@@ -238,12 +238,11 @@ __device__ __forceinline__ int max_shell(const GridView &g, int cx, int cy, int 
 }
 
 // ---- k nearest (<= k, distance < radius if radius > 0), sorted ascending, in LDS columns [slot][thread]
-// Selection is "replace the maximum": the list stays UNSORTED while candidates stream by, its largest element (in the total
-// order (d2, original index)) and that element's slot live in registers; an accepted candidate overwrites the maximum and
-// the maximum is found again by one branch-free pass over the k slots.  A sorted insertion costs every lane of the wave the
-// longest shift chain of any lane at every candidate (PMC: 71 k instructions per 64 queries, 53 % of them scalar loop
-// control); here a wave pays one fixed k-slot pass when any of its lanes accepts.  The list is sorted once at the end, so
-// callers see the same ascending order (and the same summation order) as before.
+// Selection keeps the list as a binary MAX-HEAP in the total order (d2, original index) while candidates stream by: the root
+// is the current k-th neighbour, an accepted candidate replaces it and sifts down (<= log2 k levels).  A sorted insertion
+// costs every lane of the wave the longest shift chain of any lane at every candidate (PMC of that form: 71 k instructions
+// per 64 queries, 53 % of them scalar loop control; k_normals 2.9 ms at 1 M points, 1.96 ms with a re-scanned unsorted list).
+// The list is sorted once at the end, so callers see the same ascending order (and summation order) as before.
 constexpr int KNN_BLOCK = 64;
 template <bool unused = true>
 __device__ __forceinline__ int knn_query(const GridView &g, double qx, double qy, double qz, int k, double radius,
@@ -251,23 +250,36 @@ __device__ __forceinline__ int knn_query(const GridView &g, double qx, double qy
     const int t = threadIdx.x;
     const double r2 = radius > 0 ? radius * radius : 1e300;
     int cnt = 0;
-    double maxd = 0.0;      // valid when cnt == k: the list's largest (d2, index) and its slot
-    int maxpos = 0, maxslot = 0;
+    double maxd = 0.0;      // valid when cnt == k: the heap's root (the largest (d2, index) of the list)
+    int maxslot = 0;
     const int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
     const int smax = max_shell(g, min(max(cx, 0), g.nx - 1), min(max(cy, 0), g.ny - 1), min(max(cz, 0), g.nz - 1)) + 1;
     // total order (d2, original index): exact-distance ties are common on voxelised / fp32-rounded clouds, and the oracle
     // breaks them the same way; the index loads stay off the hot path (only on an exact tie)
-    auto find_max = [&]() {
-        double m = sd[t];
-        int mp = 0, ms = si[t];
-        for (int j = 1; j < k; j++) {
-            const double v = sd[j * KNN_BLOCK + t];
-            const int vs = si[j * KNN_BLOCK + t];
-            bool gt = v > m;
-            if (v == m) gt = g.idx[vs] > g.idx[ms];
-            m = gt ? v : m; mp = gt ? j : mp; ms = gt ? vs : ms;
+    auto greater = [&](double da, int sa, double db, int sb) {
+        bool gt = da > db;
+        if (da == db) gt = g.idx[sa] > g.idx[sb];
+        return gt;
+    };
+    // puts (d2, i) at heap position pos and lets it sink to its place among the first n entries
+    auto sift_down = [&](int pos, double d2, int i, int n) {
+        for (;;) {
+            int c = 2 * pos + 1;
+            if (c >= n) break;
+            double cd = sd[c * KNN_BLOCK + t];
+            int cs = si[c * KNN_BLOCK + t];
+            if (c + 1 < n) {
+                const double rd = sd[(c + 1) * KNN_BLOCK + t];
+                const int rs = si[(c + 1) * KNN_BLOCK + t];
+                if (greater(rd, rs, cd, cs)) { c++; cd = rd; cs = rs; }
+            }
+            if (!greater(cd, cs, d2, i)) break;
+            sd[pos * KNN_BLOCK + t] = cd;
+            si[pos * KNN_BLOCK + t] = cs;
+            pos = c;
         }
-        maxd = m; maxpos = mp; maxslot = ms;
+        sd[pos * KNN_BLOCK + t] = d2;
+        si[pos * KNN_BLOCK + t] = i;
     };
     // candidates are fetched four at a time from clamped slots (no branch around a load)
     auto visit = [&](int b, int e) {
@@ -288,15 +300,13 @@ __device__ __forceinline__ int knn_query(const GridView &g, double qx, double qy
                 if (cnt < k) {
                     sd[cnt * KNN_BLOCK + t] = d2;
                     si[cnt * KNN_BLOCK + t] = i;
-                    if (++cnt == k) find_max();
-                } else {
-                    bool acc = d2 < maxd;
-                    if (d2 == maxd) acc = g.idx[i] < g.idx[maxslot];
-                    if (acc) {
-                        sd[maxpos * KNN_BLOCK + t] = d2;
-                        si[maxpos * KNN_BLOCK + t] = i;
-                        find_max();
+                    if (++cnt == k) {                       // list full: make it a heap
+                        for (int p = k / 2 - 1; p >= 0; p--) sift_down(p, sd[p * KNN_BLOCK + t], si[p * KNN_BLOCK + t], k);
+                        maxd = sd[t]; maxslot = si[t];
                     }
+                } else if (greater(maxd, maxslot, d2, i)) {
+                    sift_down(0, d2, i, k);
+                    maxd = sd[t]; maxslot = si[t];
                 }
             }
         }
@@ -309,20 +319,16 @@ __device__ __forceinline__ int knn_query(const GridView &g, double qx, double qy
         if (radius > 0 && reach >= radius) break;
         if (cnt == k && maxd <= reach * reach) break;
     }
-    // ascending (d2, index): insertion sort of the final list, once per query
-    for (int a = 1; a < cnt; a++) {
-        const double d2 = sd[a * KNN_BLOCK + t];
-        const int i = si[a * KNN_BLOCK + t];
-        int pos = a;
-        while (pos > 0) {
-            const double pd = sd[(pos - 1) * KNN_BLOCK + t];
-            if (!(pd > d2 || (pd == d2 && g.idx[si[(pos - 1) * KNN_BLOCK + t]] > g.idx[i]))) break;
-            sd[pos * KNN_BLOCK + t] = pd;
-            si[pos * KNN_BLOCK + t] = si[(pos - 1) * KNN_BLOCK + t];
-            pos--;
-        }
-        sd[pos * KNN_BLOCK + t] = d2;
-        si[pos * KNN_BLOCK + t] = i;
+    // ascending (d2, index): a full list is a heap, so heap-sort it in place (pop the maximum to the end, k - 1 times);
+    // a list that never filled is in arrival order: heapify it first
+    if (cnt < k)
+        for (int p = cnt / 2 - 1; p >= 0; p--) sift_down(p, sd[p * KNN_BLOCK + t], si[p * KNN_BLOCK + t], cnt);
+    for (int n = cnt - 1; n > 0; n--) {
+        const double ld = sd[n * KNN_BLOCK + t], rd = sd[t];
+        const int ls = si[n * KNN_BLOCK + t], rs = si[t];
+        sd[n * KNN_BLOCK + t] = rd;
+        si[n * KNN_BLOCK + t] = rs;
+        sift_down(0, ld, ls, n);
     }
     return cnt;
 }
