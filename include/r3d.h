@@ -181,7 +181,9 @@ typedef struct {
     double loop_ms;     /* host wall time of the evaluate / solve loop (iterations + 1 evaluations) */
 } r3d_icp_stats;
 /* src_normals: GICP only (covariances C = I - (1-eps) n n^T, as Open3D derives them from normals);
- * tgt_normals: point-to-plane and GICP.  init4x4 may be NULL (identity).  T4x4: row-major result. */
+ * tgt_normals: point-to-plane and GICP.  init4x4 may be NULL (identity).  T4x4: row-major result.
+ * The loop (correspondences, statistics, convergence test, update) runs on the device; the host enqueues evaluations in batches
+ * and reads the loop state once per batch, so `iterations` / `converged` are exactly those of the sequential loop. */
 int r3d_icp(r3d_ctx *ctx, const r3d_icp_params *p, const double *src, int64_t ns, const double *src_normals, const double *tgt,
             int64_t nt, const double *tgt_normals, const double *init4x4, double *T4x4, r3d_icp_stats *stats);
 
