@@ -197,12 +197,15 @@ __device__ __forceinline__ void for_shell_rows(const GridView &g, double px, dou
         const double lo = o + (double)c * g.cell, hi = lo + g.cell;
         return q < lo ? lo - q : (q > hi ? q - hi : 0.0);
     };
-    for (int dz = -s; dz <= s; dz++) {
+    // rows are taken centre-out (0, -1, +1, -2, ...): near rows tighten the bound before the far ones are looked at
+    for (int iz = 0; iz <= 2 * s; iz++) {
+        const int dz = (iz & 1) ? -((iz + 1) >> 1) : (iz >> 1);
         const int z = cz + dz;
         if (z < 0 || z >= g.nz) continue;
         const double sz = slab(pz, g.oz, z);
         if (sz * sz * SLK > bound()) continue;
-        for (int dy = -s; dy <= s; dy++) {
+        for (int iy = 0; iy <= 2 * s; iy++) {
+            const int dy = (iy & 1) ? -((iy + 1) >> 1) : (iy >> 1);
             const int y = cy + dy;
             if (y < 0 || y >= g.ny) continue;
             const double sy = slab(py, g.oy, y), syz = sy * sy + sz * sz, bnd = bound();
