@@ -844,11 +844,21 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
 __device__ __forceinline__ void nn_outer_shells(const GridView &g, double px, double py, double pz, int cx, int cy, int cz, int smax,
                                                 double &best, int &bi) {
     auto visit = [&](int b, int e) {
-        for (int j = b; j < e; j++) {
-            double dx = g.pts[(int64_t)j * 3] - px, dy = g.pts[(int64_t)j * 3 + 1] - py, dz = g.pts[(int64_t)j * 3 + 2] - pz;
-            double d2 = dx * dx + dy * dy + dz * dz;
-            if (d2 <= best) {
-                if (d2 < best || (bi >= 0 && g.idx[j] < g.idx[bi])) { best = d2; bi = j; }
+        for (int j0 = b; j0 < e; j0 += 4) {       // four candidates per round trip, clamped slots (no branch around a load)
+            double X[4], Y[4], Z[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int64_t jj = min(j0 + u, e - 1);
+                X[u] = g.pts[jj * 3]; Y[u] = g.pts[jj * 3 + 1]; Z[u] = g.pts[jj * 3 + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + u;
+                const double dx = X[u] - px, dy = Y[u] - py, dz = Z[u] - pz;
+                const double d2 = dx * dx + dy * dy + dz * dz;
+                if (j < e && d2 <= best) {
+                    if (d2 < best || (bi >= 0 && g.idx[j] < g.idx[bi])) { best = d2; bi = j; }
+                }
             }
         }
     };
