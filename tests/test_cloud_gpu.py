@@ -136,7 +136,8 @@ def test_registration_matches_oracle_iteration_for_iteration(r3d, synth, mode, n
     if name == "gicp":
         kw["target_cov"] = co.covariances_from_normals(tn)
         kw["source_cov"] = co.covariances_from_normals(sn)
-    for max_it in (1, 3, 40):
+    # 0: one evaluation, no update; 7 / 8 / 9: either side of the batch of eight evaluations the host enqueues at a time
+    for max_it in (0, 1, 3, 7, 8, 9, 40):
         want = co.registration(src, tgt, 0.02, mode=name, max_iteration=max_it, **kw)
         got = r3d.cloud_ops.registration(src, tgt, 0.02, mode=mode, max_iteration=max_it, source_normals=sn, target_normals=tn)
         assert got["iterations"] == want["iterations"]
