@@ -1426,7 +1426,10 @@ __host__ __device__ bool solve6_to_matrix(const double *s, double U[16]) {
     for (int i = 0; i < 6; i++) y[i] /= Dg[i];
     for (int i = 5; i >= 0; i--) { x[i] = y[i]; for (int k = i + 1; k < 6; k++) x[i] -= L[k][i] * x[k]; }
     // TransformVector6dToMatrix4d: R = Rz(x2) Ry(x1) Rx(x0)
-    const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cc = cos(x[2]), sc = sin(x[2]);
+    double ca, sa, cb, sb, cc, sc;   // one range reduction per angle (the update runs in a single GPU thread)
+    sincos(x[0], &sa, &ca);
+    sincos(x[1], &sb, &cb);
+    sincos(x[2], &sc, &cc);
     const double R[9] = {cc * cb, cc * sb * sa - sc * ca, cc * sb * ca + sc * sa, sc * cb, sc * sb * sa + cc * ca, sc * sb * ca - cc * sa,
                          -sb, cb * sa, cb * ca};
     for (int i = 0; i < 3; i++) {
