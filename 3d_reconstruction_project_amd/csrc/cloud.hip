@@ -816,25 +816,27 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
         nn_block_global(g, px, py, pz, cx, cy, cz, best, bi);
         return;
     }
-    // ordinal -> slot: the record with the largest ordinal base not above it
-    const int o[3] = {k1 & 1023, k2 & 1023, k3 & 1023};
-    int jb[3] = {sRun[tid], sRun[tid], sRun[tid]}, ob[3] = {0, 0, 0};
-    for (int k = 1; k < nr; k++) {
-        const int b_ = sRun[(k * 4) * B + tid], o_ = sRun[(k * 4 + 1) * B + tid];
-#pragma unroll
-        for (int q = 0; q < 3; q++)
-            if (o[q] >= o_) { jb[q] = b_; ob[q] = o_; }
-    }
-    const int kk[3] = {k1, k2, k3};
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-        const bool have = kk[q] != KINF;
-        const int j = have ? jb[q] + (o[q] - ob[q]) : 0;   // slot 0 is a valid address: no branch around the loads
+    // ordinal -> slot: the record with the largest ordinal base not above it.  The best candidate is always evaluated; the
+    // second and third only when they lie inside the margin (about one query in a hundred), in a branch of their own
+    auto slot_of = [&](int o) {
+        int jb = sRun[tid], ob = 0;
+        for (int k = 1; k < nr; k++) {
+            const int b_ = sRun[(k * 4) * B + tid], o_ = sRun[(k * 4 + 1) * B + tid];
+            if (o >= o_) { jb = b_; ob = o_; }
+        }
+        return jb + (o - ob);
+    };
+    auto exact = [&](int j) {
         const double dx = g.pts[(int64_t)j * 3] - px, dy = g.pts[(int64_t)j * 3 + 1] - py, dz = g.pts[(int64_t)j * 3 + 2] - pz;
         const double d2 = dx * dx + dy * dy + dz * dz;
-        if (have && __int_as_float(kk[q] & ~1023) <= thr2 && d2 <= best) {
+        if (d2 <= best) {
             if (d2 < best || (bi >= 0 && g.idx[j] < g.idx[bi])) { best = d2; bi = j; }
         }
+    };
+    exact(slot_of(k1 & 1023));
+    if (k2 != KINF && __int_as_float(k2 & ~1023) <= thr2) {
+        exact(slot_of(k2 & 1023));
+        if (k3 != KINF && __int_as_float(k3 & ~1023) <= thr2) exact(slot_of(k3 & 1023));
     }
 }
 
