@@ -137,7 +137,20 @@ __global__ void __launch_bounds__(256) k_voxel_mean(const double *__restrict__ a
     if (s >= nseg) return;
     int b = starts[s], e = s + 1 < nseg ? starts[s + 1] : (int)n;
     double x = 0, y = 0, z = 0;
-    for (int i = b; i < e; i++) { int64_t j = idx[i]; x += a[j * 3]; y += a[j * 3 + 1]; z += a[j * 3 + 2]; }
+    // eight members per round trip: indices first, then all eight gathers, then the additions in their original order (a
+    // member at a time costs two dependent round trips each, and a wave waits for its most populated voxel: 1.02 ms for the
+    // 7.6 M points of an 8 MP view, a fifth of the GPU time of the whole view chain)
+    for (int i0 = b; i0 < e; i0 += 8) {
+        int64_t j[8];
+        double X[8], Y[8], Z[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) j[u] = idx[min(i0 + u, e - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { X[u] = a[j[u] * 3]; Y[u] = a[j[u] * 3 + 1]; Z[u] = a[j[u] * 3 + 2]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i0 + u < e) { x += X[u]; y += Y[u]; z += Z[u]; }
+    }
     double c = (double)(e - b);
     out[s * 3] = x / c; out[s * 3 + 1] = y / c; out[s * 3 + 2] = z / c;
 }
