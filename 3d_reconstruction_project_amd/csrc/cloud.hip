@@ -721,7 +721,7 @@ __global__ void __launch_bounds__(256) k_pack_q10(GridView g, int64_t n, unsigne
 __device__ __forceinline__ int med3_i32(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
 
 __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, double py, double pz, int cx, int cy, int cz, double r2,
-                                             double &best, int &bi, int *__restrict__ sRun /* [32][ICP_BLOCK] */) {
+                                             double &best, int &bi, int *__restrict__ sRun /* [18][ICP_BLOCK] */) {
     constexpr int B = 256;   // = ICP_BLOCK (declared below)
     const int tid = threadIdx.x;
     const int xa = cx - 1, xb = cx + 1;
@@ -785,9 +785,11 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
     const float thr = fminf(thr_r, thr_of(__int_as_float(k1 & ~1023)) * 1.0003f);   // (key truncation: the key is below f by < 2^-13)
     const bool trim = de == 3 && xa == x0;         // the run is exactly the cells cx-1, cx, cx+1 (no clamping at the grid border)
     const float sxl = (qxc - 1024.f) * (qxc - 1024.f), sxh = (2048.f - qxc) * (2048.f - qxc);
-    sRun[tid] = rb[0];                             // record 0: the centre row (ordinal 0)
-    sRun[B + tid] = 0;
-    int nr = 1, obase = (re[0] - rb[0] + 3) & ~3;
+    // a record is two words: first slot, and length | row << 20 (lengths are below 1024); ordinal bases are the running sum of
+    // the padded lengths, recomputed by the one decode at the end.  Record 0: the centre row (ordinal 0)
+    sRun[tid] = rb[0];
+    sRun[B + tid] = re[0] - rb[0];
+    int nr = 1;
 #pragma unroll
     for (int q = 1; q < 9; q++) {
         const int r = ORD[q], ry = r % 3, rz = r / 3;
@@ -796,11 +798,8 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
         // a full run (cells cx-1, cx, cx+1) also drops an end cell that is too far in x
         const int b_ = trim && sxl + syz > thr ? rm1[q] : rb[q], e_ = trim && sxh + syz > thr ? rm2[q] : re[q];
         if (re[q] > rb[q] && e_ > b_ && syz <= thr) {   // (a row outside the grid has re == rb and meaningless cell boundaries)
-            sRun[(nr * 4) * B + tid] = b_;
-            sRun[(nr * 4 + 1) * B + tid] = obase;
-            sRun[(nr * 4 + 2) * B + tid] = e_;
-            sRun[(nr * 4 + 3) * B + tid] = r;
-            obase += (e_ - b_ + 3) & ~3;
+            sRun[(nr * 2) * B + tid] = b_;
+            sRun[(nr * 2 + 1) * B + tid] = (e_ - b_) | (r << 20);
             nr++;
         }
     }
@@ -810,9 +809,10 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
         for (;;) {
             if (j0 >= e) {
                 if (k >= nr) break;
-                j0 = sRun[(k * 4) * B + tid];
-                e = sRun[(k * 4 + 2) * B + tid];
-                const int r = sRun[(k * 4 + 3) * B + tid];
+                j0 = sRun[(k * 2) * B + tid];
+                const int lr = sRun[(k * 2 + 1) * B + tid];
+                e = j0 + (lr & 0xfffff);
+                const int r = lr >> 20;
                 const int rz = (r * 11) >> 5, ry = r - 3 * rz;
                 qyr = qyc - 0.5f - 1024.f * (float)ry;
                 qzr = qzc - 0.5f - 1024.f * (float)rz;
@@ -832,9 +832,10 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
     // ordinal -> slot: the record with the largest ordinal base not above it.  The best candidate is always evaluated; the
     // second and third only when they lie inside the margin (about one query in a hundred), in a branch of their own
     auto slot_of = [&](int o) {
-        int jb = sRun[tid], ob = 0;
+        int jb = sRun[tid], ob = 0, next = ((sRun[B + tid] & 0xfffff) + 3) & ~3;
         for (int k = 1; k < nr; k++) {
-            const int b_ = sRun[(k * 4) * B + tid], o_ = sRun[(k * 4 + 1) * B + tid];
+            const int b_ = sRun[(k * 2) * B + tid], o_ = next;
+            next += ((sRun[(k * 2 + 1) * B + tid] & 0xfffff) + 3) & ~3;
             if (o >= o_) { jb = b_; ob = o_; }
         }
         return jb + (o - ob);
@@ -966,7 +967,7 @@ __global__ void __launch_bounds__(ICP_BLOCK, 3) k_icp_eval(GridView g, const dou
                                                         const IcpState *__restrict__ st, double max_dist, double eps, double *__restrict__ partial,
                                                         int *__restrict__ corr /* optional [ns] target original index or -1 */) {
     static_assert(ICP_BLOCK == 256, "nn_block_q10 assumes 256 threads");
-    __shared__ int sRun[SEARCH == SEARCH_Q10 ? 36 * ICP_BLOCK : 1];
+    __shared__ int sRun[SEARCH == SEARCH_Q10 ? 18 * ICP_BLOCK : 1];
     if (st->done) return;                        // the loop ended in an earlier launch of this batch (uniform)
     const Rigid T = load_rigid(st);
     double acc[ICP_SLOTS];
