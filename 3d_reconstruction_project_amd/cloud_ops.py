@@ -11,6 +11,8 @@ _dp = ctypes.POINTER(ctypes.c_double)
 _lib.register({
     "r3d_voxel_downsample": ([_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_double, _vp, _vp, _vp,
                               ctypes.POINTER(ctypes.c_int64)], ctypes.c_int),
+    "r3d_voxel_downsample_tensor": ([_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_double, _vp, _vp, _vp,
+                                     ctypes.POINTER(ctypes.c_int64)], ctypes.c_int),
     "r3d_estimate_normals": ([_vp, _vp, ctypes.c_int64, ctypes.c_double, ctypes.c_int32, _vp, _vp], ctypes.c_int),
     "r3d_neighbor_score": ([_vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_double, _vp], ctypes.c_int),
     "r3d_reproject_disparity": ([_vp, _vp, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _vp,
@@ -20,6 +22,7 @@ _lib.register({
                                     ctypes.POINTER(ctypes.c_int64)], ctypes.c_int),
     "r3d_knn_graph": ([_vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_double, _vp, _vp], ctypes.c_int),
     "r3d_orient_normals": ([_vp, _vp, ctypes.c_int64, ctypes.c_int32, _vp], ctypes.c_int),
+    "r3d_orient_normals_graph": ([_vp, _vp, ctypes.c_int64, ctypes.c_int32, _vp, ctypes.c_int64, _vp], ctypes.c_int),
     "r3d_transform_points": ([_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int32, _vp], ctypes.c_int),
     "r3d_icp": ([_vp, ctypes.POINTER(_lib.IcpParams), _vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp,
                  ctypes.POINTER(_lib.IcpStats)], ctypes.c_int),
@@ -47,7 +50,9 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(_vp)
 
 
-def voxel_down_sample(points, voxel, colors=None, normals=None, ctx=None):
+def voxel_down_sample(points, voxel, colors=None, normals=None, ctx=None, tensor=False):
+    """Legacy voxel_down_sample (grid origin min_bound - voxel/2, float64 means); tensor=True: the o3d.t method on a Float32
+    cloud (origin 0, float32 keys and means; pointcloud_processing.py:27).  Voxels come out in lexicographic key order."""
     ctx = ctx or _lib.default_context()
     p, c, n = _c(points), _c(colors), _c(normals)
     N = len(p)
@@ -57,8 +62,8 @@ def voxel_down_sample(points, voxel, colors=None, normals=None, ctx=None):
     oc = np.empty((N, 3)) if c is not None else None
     on = np.empty((N, 3)) if n is not None else None
     m = ctypes.c_int64()
-    ctx.call("r3d_voxel_downsample", _ptr(p), _ptr(c), _ptr(n), N, float(voxel), _ptr(op), _ptr(oc), _ptr(on),
-             ctypes.byref(m))
+    ctx.call("r3d_voxel_downsample_tensor" if tensor else "r3d_voxel_downsample", _ptr(p), _ptr(c), _ptr(n), N, float(voxel),
+             _ptr(op), _ptr(oc), _ptr(on), ctypes.byref(m))
     m = m.value
     return op[:m].copy(), (oc[:m].copy() if oc is not None else None), (on[:m].copy() if on is not None else None)
 
@@ -68,6 +73,8 @@ def estimate_normals(points, radius, max_nn, prev_normals=None, ctx=None):
     ctx = ctx or _lib.default_context()
     p, pn = _c(points), _c(prev_normals)
     out = np.empty_like(p)
+    if len(p) == 0:                      # Open3D returns the empty cloud unchanged
+        return out
     ctx.call("r3d_estimate_normals", _ptr(p), len(p), float(radius) if radius else -1.0, int(max_nn), _ptr(pn), _ptr(out))
     return out
 
@@ -123,22 +130,41 @@ def knn_graph(points, k, radius=0.0, want_d2=True, ctx=None):
     return nbr, d2
 
 
-def orient_normals(points, normals, k=100, ctx=None):
-    """orient_normals_consistent_tangent_plane(k): returns the re-oriented copy of `normals`."""
+def orient_normals(points, normals, k=100, delaunay_edges=None, ctx=None):
+    """orient_normals_consistent_tangent_plane(k): returns the re-oriented copy of `normals`.  delaunay_edges ([m,2] int):
+    edges of the cloud's Delaunay tetrahedralisation -> the exact Open3D graph (r3d_orient_normals_graph); None -> the
+    k-NN-graph-only variant (r3d_orient_normals, a documented deviation)."""
     ctx = ctx or _lib.default_context()
     p = _c(points)
     n = np.ascontiguousarray(normals, dtype=np.float64).reshape(-1, 3).copy()
-    ctx.call("r3d_orient_normals", _ptr(p), len(p), int(k), _ptr(n))
+    if len(p) == 0:
+        return n
+    if delaunay_edges is None:
+        ctx.call("r3d_orient_normals", _ptr(p), len(p), int(k), _ptr(n))
+    else:
+        e = np.ascontiguousarray(delaunay_edges, dtype=np.int32).reshape(-1, 2)
+        ctx.call("r3d_orient_normals_graph", _ptr(p), len(p), int(k), e.ctypes.data_as(_vp), len(e), _ptr(n))
     return n
 
 
 def statistical_outlier_mask(points, nb_neighbors, std_ratio, ctx=None):
-    """remove_statistical_outlier(nb_neighbors, std_ratio): keep iff score < mean + ratio * std(ddof=1)."""
-    a = neighbor_score(points, k=nb_neighbors, ctx=ctx)
-    return a < a.mean() + std_ratio * a.std(ddof=1)
+    """remove_statistical_outlier(nb_neighbors, std_ratio) (pointcloud_processing.py:35) [recalled RemoveStatisticalOutliers]:
+    score a_i = mean distance to the k nearest (self included); the cloud mean sums the scores > 0 and divides by the number
+    of points, the deviation sums over scores > 0 and divides by n - 1; keep iff 0 < a_i < mean + ratio * std.  Scores of 0
+    need >= k coincident points; without them this is the plain mean / std(ddof=1) rule the recorded PLY files verify."""
+    n = len(_c(points))
+    if n == 0:
+        return np.zeros(0, bool)
+    a = neighbor_score(points, k=min(int(nb_neighbors), n), ctx=ctx)
+    pos = a > 0
+    mean = a[pos].sum() / n
+    std = np.sqrt(((a[pos] - mean) ** 2).sum() / (n - 1)) if n > 1 else 0.0
+    return pos & (a < mean + std_ratio * std)
 
 
 def radius_outlier_mask(points, nb_points, radius, ctx=None):
+    if len(_c(points)) == 0:
+        return np.zeros(0, bool)
     return neighbor_score(points, count_radius=radius, ctx=ctx) > nb_points
 
 

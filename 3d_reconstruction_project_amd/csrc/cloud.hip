@@ -17,6 +17,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "r3d_internal.h"
 
@@ -68,6 +70,11 @@ __global__ void __launch_bounds__(256) k_cell_keys(const double *__restrict__ p,
     int cx, cy, cz;
     if (key_order == 1) {  // voxel keys: the legacy index is floor((p - origin) / voxel) with a true division
         cx = (int)floor((p[i * 3] - ox) / cell); cy = (int)floor((p[i * 3 + 1] - oy) / cell); cz = (int)floor((p[i * 3 + 2] - oz) / cell);
+    } else if (key_order == 3) {  // tensor voxel keys: floor(float(p) / float(voxel)) in float32, grid origin 0; ox..oz = smallest key
+        const float v = (float)cell;
+        cx = (int)((long long)floorf((float)p[i * 3] / v) - (long long)ox);
+        cy = (int)((long long)floorf((float)p[i * 3 + 1] / v) - (long long)oy);
+        cz = (int)((long long)floorf((float)p[i * 3 + 2] / v) - (long long)oz);
     } else {               // search grid: must agree with cell_coord() used by the queries
         const double inv = 1.0 / cell;
         cx = cell_coord(p[i * 3], ox, inv); cy = cell_coord(p[i * 3 + 1], oy, inv); cz = cell_coord(p[i * 3 + 2], oz, inv);
@@ -88,7 +95,7 @@ __global__ void __launch_bounds__(256) k_cell_keys(const double *__restrict__ p,
         };
         k = spread((unsigned long long)cx) | spread((unsigned long long)cy) << 1 | spread((unsigned long long)cz) << 2;
     } else {
-        k = key_order == 0 ? ((unsigned long long)cz * ny + cy) * nx + cx : ((unsigned long long)cx * ny + cy) * nz + cz;
+        k = key_order == 0 ? ((unsigned long long)cz * ny + cy) * nx + cx : ((unsigned long long)cx * ny + cy) * nz + cz;   // 1 and 3: z fastest
     }
     keys[i] = k;
     vals[i] = (int)i;
@@ -153,6 +160,28 @@ __global__ void __launch_bounds__(256) k_voxel_mean(const double *__restrict__ a
     }
     double c = (double)(e - b);
     out[s * 3] = x / c; out[s * 3 + 1] = y / c; out[s * 3 + 2] = z / c;
+}
+
+// tensor (o3d.t) voxel_down_sample: members rounded to float32, summed in float32 in original order, divided by a float32 count
+__global__ void __launch_bounds__(256) k_voxel_mean_f32(const double *__restrict__ a, const int *__restrict__ idx, const int *__restrict__ starts,
+                                                        int64_t nseg, int64_t n, double *__restrict__ out) {
+    int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= nseg) return;
+    int b = starts[s], e = s + 1 < nseg ? starts[s + 1] : (int)n;
+    float x = 0, y = 0, z = 0;
+    for (int i0 = b; i0 < e; i0 += 8) {
+        int64_t j[8];
+        float X[8], Y[8], Z[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) j[u] = idx[min(i0 + u, e - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { X[u] = (float)a[j[u] * 3]; Y[u] = (float)a[j[u] * 3 + 1]; Z[u] = (float)a[j[u] * 3 + 2]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i0 + u < e) { x += X[u]; y += Y[u]; z += Z[u]; }
+    }
+    const float c = (float)(e - b);
+    out[s * 3] = (double)(x / c); out[s * 3 + 1] = (double)(y / c); out[s * 3 + 2] = (double)(z / c);
 }
 
 // ------------------------------------------------------------------------------------------------ search
@@ -1545,7 +1574,7 @@ struct VoxelSegs {
     int *idx = nullptr, *starts = nullptr;
     int64_t nseg = 0;
 };
-int voxel_segments(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, double voxel, VoxelSegs &V) {
+int voxel_segments(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, double voxel, VoxelSegs &V, bool tensor_grid = false) {
     double mn[3], mx[3];
     int rc;
     if ((rc = cloud_bbox(ctx, ar, d_p, n, mn, mx))) return rc;
@@ -1553,14 +1582,21 @@ int voxel_segments(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, dou
     int dims[3];
     double total = 1;
     for (int a = 0; a < 3; a++) {
-        org[a] = mn[a] - 0.5 * voxel;  // legacy: voxel_min_bound = min_bound - voxel_size * 0.5
-        dims[a] = (int)std::floor((mx[a] - org[a]) / voxel) + 2;
+        if (tensor_grid) {   // o3d.t: key = floor(float(p) / float(voxel)), origin 0; float division by a positive constant is monotonic
+            const double k0 = std::floor((float)mn[a] / (float)voxel), k1 = std::floor((float)mx[a] / (float)voxel);
+            if (!(std::fabs(k0) < 9e15 && std::fabs(k1) < 9e15 && k1 - k0 < 2.0e9)) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "voxel_downsample: voxel grid too fine for the extent of the cloud");
+            org[a] = k0;
+            dims[a] = (int)(k1 - k0) + 1;
+        } else {
+            org[a] = mn[a] - 0.5 * voxel;  // legacy: voxel_min_bound = min_bound - voxel_size * 0.5
+            dims[a] = (int)std::floor((mx[a] - org[a]) / voxel) + 2;
+        }
         total *= dims[a];
     }
     if (total >= 1.8e19) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "voxel_downsample: voxel grid exceeds 2^64 cells");
     unsigned long long *keys;
     // key_order 1: exact legacy index floor((p - origin) / voxel), z fastest => output in lexicographic (kx,ky,kz) order
-    if ((rc = sort_by_cell(ctx, ar, d_p, n, org, voxel, dims, 1, &keys, &V.idx))) return rc;
+    if ((rc = sort_by_cell(ctx, ar, d_p, n, org, voxel, dims, tensor_grid ? 3 : 1, &keys, &V.idx))) return rc;
     int *flags = (int *)ar.get((size_t)n * 4), *scan = (int *)ar.get((size_t)n * 4);
     V.starts = (int *)ar.get((size_t)n * 4);
     if (ar.rc) return ar.rc;
@@ -1725,10 +1761,23 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
         R3D_HIP(ctx, hipGetLastError());
         R3D_HIP(ctx, hipMemcpyAsync(hst, d_st, sizeof *hst, hipMemcpyDeviceToHost, ctx->stream));
         R3D_HIP(ctx, hipEventRecord(ctx->icp_ev, ctx->stream));
-        for (;;) {
+        // Bounded wait.  A tight spin for the first 200 us (a batch of a small cloud is shorter than a sleep), then the thread
+        // yields between polls: a bare hipEventQuery spin hammers the runtime's stream lock, which the completion handlers of a
+        // profiler's dispatch interception also need (a rocprofv3 --pmc pass of the 1 M-point loop made no progress for 7
+        // minutes with the bare spin).  The deadline scales with the work enqueued (serialised counter passes are ~100x
+        // slower than a plain run); on expiry the call fails with the last state read so the caller exits non-zero.
+        const auto t_poll = std::chrono::steady_clock::now();
+        const double deadline_s = 20.0 + 2e-6 * (double)(ns + nt) * ICP_BATCH;
+        for (unsigned spins = 0;; spins++) {
             const hipError_t q = hipEventQuery(ctx->icp_ev);
             if (q == hipSuccess) break;
             if (q != hipErrorNotReady) return r3d_fail(ctx, R3D_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+            if ((spins & 63) != 63) continue;
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_poll).count();
+            if (waited > deadline_s)
+                return r3d_fail(ctx, R3D_E_HIP, "registration loop: no completion after %.0f s (%d evaluations enqueued, last state read: %d evaluations, done=%d)",
+                                waited, enq, hst->evals, hst->done);
+            if (waited > 2e-4) std::this_thread::sleep_for(std::chrono::microseconds(waited > 5e-3 ? 200 : 20));
         }
         if (hst->done) break;
     }
@@ -1752,8 +1801,21 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
 
 extern "C" {
 
+static int voxel_downsample_impl(r3d_ctx *ctx, const double *xyz, const double *colors, const double *normals, int64_t n, double voxel,
+                                 double *out_xyz, double *out_colors, double *out_normals, int64_t *out_n, bool tensor_grid);
+
 int r3d_voxel_downsample(r3d_ctx *ctx, const double *xyz, const double *colors, const double *normals, int64_t n, double voxel,
                          double *out_xyz, double *out_colors, double *out_normals, int64_t *out_n) {
+    return voxel_downsample_impl(ctx, xyz, colors, normals, n, voxel, out_xyz, out_colors, out_normals, out_n, false);
+}
+
+int r3d_voxel_downsample_tensor(r3d_ctx *ctx, const double *xyz, const double *colors, const double *normals, int64_t n, double voxel,
+                                double *out_xyz, double *out_colors, double *out_normals, int64_t *out_n) {
+    return voxel_downsample_impl(ctx, xyz, colors, normals, n, voxel, out_xyz, out_colors, out_normals, out_n, true);
+}
+
+static int voxel_downsample_impl(r3d_ctx *ctx, const double *xyz, const double *colors, const double *normals, int64_t n, double voxel,
+                                 double *out_xyz, double *out_colors, double *out_normals, int64_t *out_n, bool tensor_grid) {
     if (!ctx) return R3D_E_BADARG;
     if (!xyz || !out_xyz || !out_n || n <= 0 || !(voxel > 0)) return r3d_fail(ctx, R3D_E_BADARG, "voxel_downsample: bad argument");
     if ((colors && !out_colors) || (normals && !out_normals)) return r3d_fail(ctx, R3D_E_BADARG, "voxel_downsample: missing output array");
@@ -1765,7 +1827,7 @@ int r3d_voxel_downsample(r3d_ctx *ctx, const double *xyz, const double *colors, 
     if (colors && (rc = upload(ctx, ar, colors, n * 3, &d_c))) return rc;
     if (normals && (rc = upload(ctx, ar, normals, n * 3, &d_n))) return rc;
     VoxelSegs V;
-    if ((rc = voxel_segments(ctx, ar, d_p, n, voxel, V))) return rc;
+    if ((rc = voxel_segments(ctx, ar, d_p, n, voxel, V, tensor_grid))) return rc;
     const int64_t nseg = V.nseg;
     double *d_out = (double *)ar.get((size_t)nseg * 24);
     if (ar.rc) return ar.rc;
@@ -1774,7 +1836,8 @@ int r3d_voxel_downsample(r3d_ctx *ctx, const double *xyz, const double *colors, 
     double *outs[3] = {out_xyz, out_colors, out_normals};
     for (int a = 0; a < 3; a++) {
         if (!ins[a]) continue;
-        k_voxel_mean<<<nbs, 256, 0, ctx->stream>>>(ins[a], V.idx, V.starts, nseg, n, d_out);
+        if (tensor_grid) k_voxel_mean_f32<<<nbs, 256, 0, ctx->stream>>>(ins[a], V.idx, V.starts, nseg, n, d_out);
+        else k_voxel_mean<<<nbs, 256, 0, ctx->stream>>>(ins[a], V.idx, V.starts, nseg, n, d_out);
         R3D_HIP(ctx, hipGetLastError());
         R3D_HIP(ctx, hipMemcpyAsync(outs[a], d_out, (size_t)nseg * 24, hipMemcpyDeviceToHost, ctx->stream));
         R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1977,62 +2040,120 @@ int r3d_knn_graph(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, double 
     return R3D_OK;
 }
 
-// orient_normals_consistent_tangent_plane(k): device k-NN graph, then sequential host work in C++ (Kruskal minimum
-// spanning tree over the edges weighted 1 - |n_i . n_j|, breadth-first sign propagation from the highest point of every
-// component).  Deterministic: edges are ordered by (weight, i, j).
-int r3d_orient_normals(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, double *normals) {
-    if (!ctx) return R3D_E_BADARG;
-    if (!xyz || !normals || n <= 0 || k < 1) return r3d_fail(ctx, R3D_E_BADARG, "orient_normals: bad argument");
-    if (n == 1) { if (normals[2] < 0) for (int a = 0; a < 3; a++) normals[a] = -normals[a]; return R3D_OK; }
-    const int kk = (int)std::min<int64_t>((int64_t)k + 1, std::min<int64_t>(n, 128));
-    std::vector<int32_t> nbr((size_t)n * kk);
-    int rc = r3d_knn_graph(ctx, xyz, n, kk, -1.0, nbr.data(), nullptr);
-    if (rc) return rc;
-    struct Edge { double w; int a, b; };
-    std::vector<Edge> edges;
-    edges.reserve((size_t)n * (kk - 1));
-    auto dotn = [&](int a, int b) { return normals[(size_t)a * 3] * normals[(size_t)b * 3] + normals[(size_t)a * 3 + 1] * normals[(size_t)b * 3 + 1] + normals[(size_t)a * 3 + 2] * normals[(size_t)b * 3 + 2]; };
-    for (int64_t i = 0; i < n; i++)
-        for (int j = 1; j < kk; j++) {
-            const int q = nbr[(size_t)i * kk + j];
-            if (q < 0 || q == i) continue;
-            const int a = (int)std::min<int64_t>(i, q), b = (int)std::max<int64_t>(i, q);
-            edges.push_back({1.0 - std::fabs(dotn(a, b)), a, b});
-        }
-    std::sort(edges.begin(), edges.end(), [](const Edge &x, const Edge &y) {
-        if (x.w != y.w) return x.w < y.w;
-        if (x.a != y.a) return x.a < y.a;
-        return x.b < y.b;
-    });
-    std::vector<int> parent(n);
+}  // extern "C" (reopened below)
+
+// orient_normals_consistent_tangent_plane(k)  (normal_estimation.py:21; Open3D legacy OrientNormalsConsistentTangentPlane
+// [recalled], which the tensor method delegates to).  Device: the k-NN graph.  Host, inside the library (sequential by nature):
+// two Kruskal spanning trees and the breadth-first sign propagation.  Edges are visited in the total order (weight, a, b).
+//   with a Delaunay edge list (r3d_orient_normals_graph): Euclidean MST of those edges (weight = squared length), re-weighted
+//   1 - |n_a . n_b|; plus the k-NN edges (the point itself counts as one of the k) that are NOT Delaunay edges -- the original
+//   tests membership against the set of ALL Delaunay edges, not only the EMST ones, and so does this; spanning tree of that
+//   graph; propagation from the point of maximum z (first on ties), whose normal is turned towards +z.
+//   without one (r3d_orient_normals): k-NN edges only, every connected component rooted at its own highest point.
+namespace {
+struct WEdge { double w; int a, b; };
+inline bool wedge_less(const WEdge &x, const WEdge &y) {
+    if (x.w != y.w) return x.w < y.w;
+    if (x.a != y.a) return x.a < y.a;
+    return x.b < y.b;
+}
+// keeps the spanning-forest edges of `edges` (sorted in place); parent is the caller's disjoint-set array (reset here)
+void kruskal_forest(std::vector<WEdge> &edges, std::vector<int> &parent, std::vector<WEdge> &forest) {
+    std::sort(edges.begin(), edges.end(), wedge_less);
+    const int64_t n = (int64_t)parent.size();
     for (int64_t i = 0; i < n; i++) parent[i] = (int)i;
     auto find = [&](int v) { while (parent[v] != v) { parent[v] = parent[parent[v]]; v = parent[v]; } return v; };
-    std::vector<int> deg(n + 1, 0);
-    std::vector<std::pair<int, int>> tree;
-    tree.reserve(n);
-    for (const Edge &e : edges) {
+    forest.clear();
+    forest.reserve(n);
+    for (const WEdge &e : edges) {
         const int ra = find(e.a), rb = find(e.b);
         if (ra == rb) continue;
         parent[ra] = rb;
-        tree.push_back({e.a, e.b});
-        deg[e.a + 1]++; deg[e.b + 1]++;
+        forest.push_back(e);
+        if ((int64_t)forest.size() == n - 1) break;
     }
+}
+
+int orient_core(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, const int32_t *del_edges, int64_t n_del, double *normals) {
+    auto dotn = [&](int a, int b) {
+        return (normals[(size_t)a * 3] * normals[(size_t)b * 3] + normals[(size_t)a * 3 + 1] * normals[(size_t)b * 3 + 1]) +
+               normals[(size_t)a * 3 + 2] * normals[(size_t)b * 3 + 2];
+    };
+    auto flip = [&](int v) { for (int a = 0; a < 3; a++) normals[(size_t)v * 3 + a] = -normals[(size_t)v * 3 + a]; };
+    // the k nearest INCLUDING the point itself (KDTreeFlann::SearchKNN(points_[v0], k)), from the device
+    const int kk = (int)std::min<int64_t>((int64_t)k, std::min<int64_t>(n, 128));
+    std::vector<int32_t> nbr((size_t)n * kk);
+    int rc = r3d_knn_graph(ctx, xyz, n, kk, -1.0, nbr.data(), nullptr);
+    if (rc) return rc;
+    std::vector<int> parent(n);
+    std::vector<WEdge> graph, forest;
+    std::vector<unsigned long long> del_keys;   // EdgeIndex = min * n + max of every Delaunay edge, sorted
+    if (del_edges) {
+        std::vector<WEdge> del;
+        del.reserve((size_t)n_del);
+        del_keys.reserve((size_t)n_del);
+        for (int64_t e = 0; e < n_del; e++) {
+            const int64_t u = del_edges[2 * e], v = del_edges[2 * e + 1];
+            if (u < 0 || v < 0 || u >= n || v >= n) return r3d_fail(ctx, R3D_E_BADARG, "orient_normals: edge %lld names a point outside the cloud", (long long)e);
+            if (u == v) continue;
+            del_keys.push_back((unsigned long long)std::min(u, v) * (unsigned long long)n + (unsigned long long)std::max(u, v));
+        }
+        std::sort(del_keys.begin(), del_keys.end());
+        del_keys.erase(std::unique(del_keys.begin(), del_keys.end()), del_keys.end());
+        for (unsigned long long key : del_keys) {
+            const int a = (int)(key / (unsigned long long)n), b = (int)(key % (unsigned long long)n);
+            const double dx = xyz[(size_t)a * 3] - xyz[(size_t)b * 3], dy = xyz[(size_t)a * 3 + 1] - xyz[(size_t)b * 3 + 1],
+                         dz = xyz[(size_t)a * 3 + 2] - xyz[(size_t)b * 3 + 2];
+            del.push_back({(dx * dx + dy * dy) + dz * dz, a, b});
+        }
+        kruskal_forest(del, parent, forest);                                           // Euclidean minimum spanning tree
+        graph.reserve(forest.size() + (size_t)n * (kk > 1 ? kk - 1 : 0));
+        for (const WEdge &e : forest) graph.push_back({1.0 - std::fabs(dotn(e.a, e.b)), e.a, e.b});
+    } else {
+        graph.reserve((size_t)n * (kk > 1 ? kk - 1 : 0));
+    }
+    const size_t n_tree_edges = graph.size();
+    for (int64_t i = 0; i < n; i++)
+        for (int j = 0; j < kk; j++) {
+            const int q = nbr[(size_t)i * kk + j];
+            if (q < 0 || q == i) continue;
+            const int a = (int)std::min<int64_t>(i, q), b = (int)std::max<int64_t>(i, q);
+            if (del_edges && std::binary_search(del_keys.begin(), del_keys.end(), (unsigned long long)a * (unsigned long long)n + (unsigned long long)b)) continue;
+            graph.push_back({0.0, a, b});
+        }
+    {   // an undirected k-NN edge appears once (graph_edges.insert in the original); weights after the de-duplication
+        auto first = graph.begin() + (std::ptrdiff_t)n_tree_edges;
+        std::sort(first, graph.end(), [](const WEdge &x, const WEdge &y) { return x.a != y.a ? x.a < y.a : x.b < y.b; });
+        graph.erase(std::unique(first, graph.end(), [](const WEdge &x, const WEdge &y) { return x.a == y.a && x.b == y.b; }), graph.end());
+        for (size_t e = n_tree_edges; e < graph.size(); e++) graph[e].w = 1.0 - std::fabs(dotn(graph[e].a, graph[e].b));
+    }
+    kruskal_forest(graph, parent, forest);
+    // adjacency of the tree (CSR)
+    std::vector<int> deg(n + 1, 0);
+    for (const WEdge &e : forest) { deg[e.a + 1]++; deg[e.b + 1]++; }
     for (int64_t i = 0; i < n; i++) deg[i + 1] += deg[i];
-    std::vector<int> adj(tree.size() * 2), fill(deg.begin(), deg.end() - 1);
-    for (auto &t : tree) { adj[fill[t.first]++] = t.second; adj[fill[t.second]++] = t.first; }
-    // components: root = highest z
-    std::vector<int> comp_root(n, -1);
-    for (int64_t i = 0; i < n; i++) {
-        const int r = find((int)i);
-        if (comp_root[r] < 0 || xyz[(size_t)i * 3 + 2] > xyz[(size_t)comp_root[r] * 3 + 2]) comp_root[r] = (int)i;
+    std::vector<int> adj(forest.size() * 2), fill(deg.begin(), deg.end() - 1);
+    for (const WEdge &e : forest) { adj[fill[e.a]++] = e.b; adj[fill[e.b]++] = e.a; }
+    // roots: the highest point of the cloud (Delaunay graph: connected), or of every component (k-NN graph only)
+    std::vector<int> roots;
+    if (del_edges) {
+        int top = 0;
+        for (int64_t i = 1; i < n; i++) if (xyz[(size_t)i * 3 + 2] > xyz[(size_t)top * 3 + 2]) top = (int)i;
+        roots.push_back(top);
+    } else {
+        auto find = [&](int v) { while (parent[v] != v) v = parent[v]; return v; };
+        std::vector<int> comp_root(n, -1);
+        for (int64_t i = 0; i < n; i++) {
+            const int r = find((int)i);
+            if (comp_root[r] < 0 || xyz[(size_t)i * 3 + 2] > xyz[(size_t)comp_root[r] * 3 + 2]) comp_root[r] = (int)i;
+        }
+        for (int64_t r = 0; r < n; r++) if (comp_root[r] >= 0) roots.push_back(comp_root[r]);
     }
     std::vector<char> seen(n, 0);
     std::vector<int> queue;
     queue.reserve(n);
-    for (int64_t r = 0; r < n; r++) {
-        const int root = comp_root[r];
-        if (root < 0) continue;
-        if (normals[(size_t)root * 3 + 2] < 0) for (int a = 0; a < 3; a++) normals[(size_t)root * 3 + a] = -normals[(size_t)root * 3 + a];
+    for (const int root : roots) {
+        if (normals[(size_t)root * 3 + 2] < 0) flip(root);      // TestAndOrientNormal((0,0,1), n_root)
         queue.clear();
         queue.push_back(root);
         seen[root] = 1;
@@ -2042,12 +2163,30 @@ int r3d_orient_normals(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, do
                 const int u = adj[e];
                 if (seen[u]) continue;
                 seen[u] = 1;
-                if (dotn(u, v) < 0) for (int a = 0; a < 3; a++) normals[(size_t)u * 3 + a] = -normals[(size_t)u * 3 + a];
+                if (dotn(u, v) < 0) flip(u);
                 queue.push_back(u);
             }
         }
     }
     return R3D_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int r3d_orient_normals(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, double *normals) {
+    if (!ctx) return R3D_E_BADARG;
+    if (!xyz || !normals || n <= 0 || k < 1) return r3d_fail(ctx, R3D_E_BADARG, "orient_normals: bad argument");
+    if (n == 1) { if (normals[2] < 0) for (int a = 0; a < 3; a++) normals[a] = -normals[a]; return R3D_OK; }
+    return orient_core(ctx, xyz, n, k, nullptr, 0, normals);
+}
+
+int r3d_orient_normals_graph(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, const int32_t *delaunay_edges, int64_t n_edges,
+                             double *normals) {
+    if (!ctx) return R3D_E_BADARG;
+    if (!xyz || !normals || !delaunay_edges || n <= 0 || k < 1 || n_edges < 0) return r3d_fail(ctx, R3D_E_BADARG, "orient_normals_graph: bad argument");
+    if (n < 4) return r3d_fail(ctx, R3D_E_BADARG, "orient_normals_graph: a tetrahedralisation needs at least 4 points");
+    return orient_core(ctx, xyz, n, k, delaunay_edges, n_edges, normals);
 }
 
 int r3d_transform_points(r3d_ctx *ctx, const double *xyz, int64_t n, const double *T4x4, int32_t rotate_only, double *out) {

@@ -18,7 +18,7 @@ class NormalEstimation:
         n = cloud_ops.estimate_normals(p32, radius, max_nn, ctx=ctx)
         if orient_k:
             from .orientation import orient_normals_consistent_tangent_plane
-            n = orient_normals_consistent_tangent_plane(p32, n, orient_k)
+            n = orient_normals_consistent_tangent_plane(p32, n, orient_k, ctx=ctx)
         return like(pcd, p32, c, n)
 
     estimate = estimate_normals

@@ -22,8 +22,8 @@ class PointCloudProcessingWithCUDA:
             pcd = filename_or_cloud
         ctx = _lib.default_context(self.device)
         p, c, n = as_arrays(pcd)
-        p = p.astype(np.float32).astype(np.float64)          # from_legacy(pcd, Float32) before the tensor down-sample
-        p, c, n = cloud_ops.voxel_down_sample(p, self.downsample_voxel_size, c, n, ctx=ctx)
+        # from_legacy(pcd, Float32) -> o3d.t voxel_down_sample (float32 keys from origin 0, float32 means) -> to_legacy
+        p, c, n = cloud_ops.voxel_down_sample(p, self.downsample_voxel_size, c, n, ctx=ctx, tensor=True)
         keep = cloud_ops.statistical_outlier_mask(p, nb_neighbors, std_ratio, ctx=ctx)
         p, c, n = p[keep], (c[keep] if c is not None else None), (n[keep] if n is not None else None)
         keep = cloud_ops.radius_outlier_mask(p, nb_points, radius, ctx=ctx)

@@ -114,6 +114,13 @@ int r3d_sgbm_debug_fetch(r3d_ctx *ctx, int16_t *cost, int16_t *hsum, int16_t *ra
 int r3d_voxel_downsample(r3d_ctx *ctx, const double *xyz, const double *colors, const double *normals, int64_t n, double voxel,
                          double *out_xyz, double *out_colors, double *out_normals, int64_t *out_n);
 
+/* replaces: o3d.t.geometry.PointCloud.voxel_down_sample(voxel) on a Float32 tensor cloud   pointcloud_processing.py:26-27,
+ * test/GICP1.py:71-72   [recalled, Open3D 0.18 reduction "mean"].  Unlike the legacy grid above: coordinates and attributes are
+ * rounded to float32, key = floor(p / voxel) evaluated in float32 with the grid origin at 0, sums and the division in float32
+ * (members added in their original order; the original's order is that of device atomics).  Outputs hold float32 values. */
+int r3d_voxel_downsample_tensor(r3d_ctx *ctx, const double *xyz, const double *colors, const double *normals, int64_t n, double voxel,
+                                double *out_xyz, double *out_colors, double *out_normals, int64_t *out_n);
+
 /* replaces: pcd.estimate_normals(KDTreeSearchParamHybrid(radius, max_nn))   pointcloud_alignment.py:27-28,
  * test/GICP1.py:77,95,97,148; tensor estimate_normals(max_nn, radius)   normal_estimation.py:20.
  * radius <= 0 selects KDTreeSearchParamKNN(max_nn).  <= max_nn nearest neighbours with distance < radius (query
@@ -150,9 +157,19 @@ int r3d_disparity_to_cloud_dev(r3d_ctx *ctx, const int16_t *d_disp, int32_t w, i
  * (normal_estimation.py:21), whose spanning-tree propagation is sequential host work.  d2 may be NULL. */
 int r3d_knn_graph(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, double radius, int32_t *nbr, double *d2);
 
-/* replaces: pcd.orient_normals_consistent_tangent_plane(k)   normal_estimation.py:21.  k-NN graph on the device, spanning
- * tree + sign propagation (sequential) on the host inside the library; normals are flipped in place. */
+/* replaces: pcd.orient_normals_consistent_tangent_plane(k)   normal_estimation.py:21   (Open3D legacy
+ * OrientNormalsConsistentTangentPlane [recalled]; the tensor method converts to legacy and calls it).
+ * r3d_orient_normals_graph is the exact form: `delaunay_edges` = n_edges (a, b) index pairs, the edges of the Delaunay
+ * tetrahedralisation of the cloud (Open3D obtains it from Qhull on the host; the Python layer does the same).  The library
+ * builds the Euclidean MST of those edges, adds the k-nearest-neighbour edges from the device graph (the point itself is one
+ * of the k) that are not Delaunay edges, weights 1 - |n_a . n_b|, takes the spanning tree and propagates the sign from the
+ * highest point (turned towards +z).  Equal weights are visited in (a, b) order (the original's order is unspecified).
+ * r3d_orient_normals is the k-NN-graph-only variant for callers without a tetrahedralisation: no Euclidean-MST edges, every
+ * connected component is rooted at its own highest point -- a DEVIATION from Open3D, not used by the drop-in classes.
+ * Spanning trees and propagation are sequential host work inside the library; normals are flipped in place. */
 int r3d_orient_normals(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, double *normals);
+int r3d_orient_normals_graph(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, const int32_t *delaunay_edges, int64_t n_edges,
+                             double *normals);
 
 /* replaces: pcd.transform(T)   pointcloud_alignment.py:42  (rotate_only != 0 for normals) ; T row-major 4x4 */
 int r3d_transform_points(r3d_ctx *ctx, const double *xyz, int64_t n, const double *T4x4, int32_t rotate_only, double *out);

@@ -12,10 +12,14 @@ call sites:
     registration_icp (P2P)     pointcloud_alignment.py:35-39
     registration_generalized_icp  test/GICP1.py:99-102
     point-to-plane             test/check2.py:151-154
+    orient_normals_consistent_tangent_plane   normal_estimation.py:21
+    tensor voxel_down_sample   pointcloud_processing.py:27, test/GICP1.py:71-72
+    scanning loops             main.py:34-54, test/GICP1.py:134-155 (fuse_loop)
 PINNED by the reference's recorded runs (tests/golden, from test/output84 and test/output): back-projection, voxel
 down-sampling, statistical outlier removal and hybrid-search PCA normals reproduce the recorded PLY files
 (tests/test_cloud_oracle.py).  ICP / GICP / point-to-plane are PARITY UNPINNED (the reference recorded no
-transforms); they are checked by analytic known-answer tests only.
+transforms); they are checked by analytic known-answer tests only.  Normal orientation and the tensor (float32,
+origin 0) voxel grid are PARITY UNPINNED as well (nothing recorded by the reference; Open3D semantics [recalled]).
 """
 import json
 import struct
@@ -110,10 +114,20 @@ def voxel_down_sample(points, voxel, colors=None, normals=None):
 
 # ------------------------------------------------------------------------------------------ outlier removal
 def statistical_outlier_mask(points, nb_neighbors, std_ratio):
-    """keep_i <=> mean of the k smallest distances (self included) < mean + ratio * std(ddof=1)."""
-    d, _ = cKDTree(points).query(points, k=nb_neighbors)
+    """RemoveStatisticalOutliers [recalled]: a_i = mean of the k smallest distances (self included); the cloud mean sums
+    only a_i > 0 but divides by the number of points, the deviation sums only a_i > 0 and divides by n - 1 (Bessel);
+    keep_i <=> 0 < a_i < mean + ratio * std.  (a_i == 0 needs >= k coincident points; without them this is the plain
+    mean / std(ddof=1) rule the recorded PLY files verify.)"""
+    n = points.shape[0]
+    if n == 0:
+        return np.zeros(0, bool)
+    d, _ = cKDTree(points).query(points, k=min(nb_neighbors, n))
+    d = d.reshape(n, -1)
     a = d.mean(axis=1)
-    return a < a.mean() + std_ratio * a.std(ddof=1)
+    pos = a > 0
+    mean = a[pos].sum() / n
+    std = np.sqrt(((a[pos] - mean) ** 2).sum() / (n - 1)) if n > 1 else 0.0
+    return pos & (a < mean + std_ratio * std)
 
 
 def radius_outlier_mask(points, nb_points, radius):
@@ -136,20 +150,33 @@ def _d2(points, idx, q):
     return (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
 
 
-def _pca_normals(points, idx_lists):
-    n = points.shape[0]
-    normals = np.zeros((n, 3))
-    covs = np.zeros((n, 3, 3))
-    for i in range(n):
-        idx = idx_lists[i]
-        if len(idx) < 3:
-            normals[i] = (0.0, 0.0, 1.0)
-            continue
-        q = points[idx]
-        c = np.cov(q.T, bias=True)
-        covs[i] = c
-        w, v = np.linalg.eigh(c)
-        normals[i] = _canon_sign(v[:, 0])
+def _pca_normals(points, idx_lists, prev_normals=None, centers=None):
+    """Population covariance of every neighbour list (centred on the query first, as the kernel and Open3D's cumulant
+    form do), eigenvector of the smallest eigenvalue; fewer than 3 neighbours -> (0,0,1).  Sign: towards prev_normals
+    when given (legacy EstimateNormals keeps an existing orientation), else the canonical one of _canon_sign."""
+    centers = points if centers is None else centers
+    n = centers.shape[0]
+    cnt = np.fromiter((len(ix) for ix in idx_lists), np.int64, n)
+    kmax = int(cnt.max()) if n else 0
+    pad = np.zeros((n, max(kmax, 1)), np.int64)
+    mask = np.arange(max(kmax, 1))[None, :] < cnt[:, None]
+    for i, ix in enumerate(idx_lists):
+        pad[i, :len(ix)] = ix
+    q = (points[pad] - centers[:, None, :]) * mask[:, :, None]
+    c = np.maximum(cnt, 1)[:, None]
+    m = q.sum(1) / c
+    covs = np.einsum("nki,nkj->nij", q, q) / c[:, :, None] - m[:, :, None] * m[:, None, :]
+    normals = np.tile(np.array([0.0, 0.0, 1.0]), (n, 1))
+    ok = cnt >= 3
+    if ok.any():
+        _, v = np.linalg.eigh(covs[ok])
+        v0 = v[:, :, 0]
+        a = np.abs(v0)
+        lead = np.where((a[:, 0] >= a[:, 1]) & (a[:, 0] >= a[:, 2]), v0[:, 0], np.where(a[:, 1] >= a[:, 2], v0[:, 1], v0[:, 2]))
+        normals[ok] = np.where((lead < 0)[:, None], -v0, v0)
+    if prev_normals is not None:
+        flip = (normals * prev_normals).sum(1) < 0
+        normals[flip] = -normals[flip]
     return normals, covs
 
 
@@ -157,7 +184,7 @@ def _nearest_total_order(points, q, k, extra=12):
     """k nearest of every query under the TOTAL ORDER (squared distance, index): exact-distance ties are common on
     voxelised clouds and a kd-tree breaks them arbitrarily.  Returns (idx [m,k], d2 [m,k])."""
     kk = min(k + extra, points.shape[0])
-    _, idx = cKDTree(points).query(q, k=kk)
+    _, idx = cKDTree(points).query(q, k=kk, workers=-1)
     if kk == 1:
         idx = idx[:, None]
     d2 = _d2(points, idx, q[:, None, :])
@@ -175,15 +202,146 @@ def hybrid_neighbors(points, radius, max_nn, queries=None):
     return [idx[i][keep[i]] for i in range(q.shape[0])]
 
 
-def estimate_normals_hybrid(points, radius, max_nn):
+def estimate_normals_hybrid(points, radius, max_nn, prev_normals=None):
     """Legacy estimate_normals(KDTreeSearchParamHybrid(radius, max_nn)): population covariance of the neighbours,
-    eigenvector of the smallest eigenvalue, (0,0,1) when fewer than 3 neighbours; sign is arbitrary."""
-    return _pca_normals(points, hybrid_neighbors(points, radius, max_nn))[0]
+    eigenvector of the smallest eigenvalue, (0,0,1) when fewer than 3 neighbours; sign is arbitrary unless the cloud
+    already carries normals (then each new normal is turned towards the old one, test/GICP1.py:148 relies on it)."""
+    return _pca_normals(points, hybrid_neighbors(points, radius, max_nn), prev_normals)[0]
 
 
-def estimate_normals_knn(points, k):
-    idx, _ = _nearest_total_order(points, points, min(k, points.shape[0]))
-    return _pca_normals(points, list(idx))[0]
+def estimate_normals_knn(points, k, queries=None):
+    """kNN normals; `queries` (indices into points) restricts the output to a subset (spot checks on large clouds)."""
+    if queries is None:
+        idx, _ = _nearest_total_order(points, points, min(k, points.shape[0]))
+        return _pca_normals(points, list(idx))[0]
+    queries = np.asarray(queries, np.int64)
+    idx, _ = _nearest_total_order(points, points[queries], min(k, points.shape[0]))
+    return _pca_normals(points, list(idx), centers=points[queries])[0]
+
+
+# ------------------------------------------------------------------------------- tensor (o3d.t) voxel grid
+def voxel_down_sample_tensor(points, voxel, colors=None, normals=None):
+    """o3d.t.geometry.PointCloud.voxel_down_sample(voxel) on a Float32 cloud (pointcloud_processing.py:26-27,
+    test/GICP1.py:71-72) [recalled, Open3D 0.18 reduction="mean"]: key = floor(p / voxel) in float32 (grid origin 0, NOT
+    the legacy min_bound - voxel/2), attributes reduced as float32 sums / float32 count.  The original's summation order is
+    that of atomic adds on the device (unspecified); here members are added in their original order, in float32.
+    Voxels come out in lexicographic key order (the original's is hash-map order).  Inputs are rounded to float32 first
+    (from_legacy(..., Float32)); returns float64 arrays holding float32 values (to_legacy)."""
+    p32 = np.asarray(points, np.float64).astype(np.float32)
+    keys = np.floor(p32 / np.float32(voxel)).astype(np.int64)
+    _, inv, cnt = np.unique(keys, axis=0, return_inverse=True, return_counts=True)
+    inv = inv.reshape(-1)
+    order = np.argsort(inv, kind="stable")
+    starts = np.concatenate([[0], np.cumsum(cnt)])
+
+    def mean32(a):
+        a32 = np.asarray(a, np.float64).astype(np.float32)[order]
+        out = np.zeros((cnt.shape[0], 3), np.float32)
+        pos = np.zeros(cnt.shape[0], np.int64)
+        live = np.arange(cnt.shape[0])
+        while live.size:                                   # member j of every voxel that still has one: sequential fp32 adds
+            out[live] = out[live] + a32[starts[live] + pos[live]]
+            pos[live] += 1
+            live = live[pos[live] < cnt[live]]
+        return (out / cnt.astype(np.float32)[:, None]).astype(np.float64)
+
+    res = [mean32(p32)]
+    if colors is not None:
+        res.append(mean32(colors))
+    if normals is not None:
+        res.append(mean32(normals))
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+# ------------------------------------------------------------------------------------- normal orientation
+def delaunay_edges(points, qhull_options="Qbb Qt"):
+    """Unique undirected edges (a < b) of the Delaunay tetrahedralisation, lexicographically sorted.  Open3D builds it with
+    Qhull ("d Qbb Qt", TetraMesh::CreateFromPointCloud [recalled]); scipy wraps the same library."""
+    from scipy.spatial import Delaunay
+    tet = Delaunay(np.asarray(points, np.float64), qhull_options=qhull_options).simplices.astype(np.int64)
+    pairs = np.concatenate([tet[:, [a, b]] for a, b in ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))], 0)
+    pairs.sort(axis=1)
+    return np.unique(pairs, axis=0)
+
+
+def kruskal(n, v0, v1, w):
+    """Minimum spanning forest, edges visited in the total order (weight, v0, v1) (the original's std::sort leaves equal
+    weights in unspecified order).  Returns the boolean mask of kept edges.  The union-find loop is oracle/graph.c."""
+    import ctypes
+    from . import sgbm_oracle
+    L = ctypes.CDLL(sgbm_oracle.build())
+    i64p = ctypes.POINTER(ctypes.c_int64)
+    L.r3d_oracle_kruskal.argtypes = [ctypes.c_int64, ctypes.c_int64, i64p, i64p, i64p, ctypes.POINTER(ctypes.c_uint8)]
+    L.r3d_oracle_kruskal.restype = ctypes.c_int64
+    v0 = np.ascontiguousarray(v0, np.int64)
+    v1 = np.ascontiguousarray(v1, np.int64)
+    order = np.ascontiguousarray(np.lexsort((v1, v0, np.asarray(w, np.float64))), np.int64)
+    kept = np.zeros(len(v0), np.uint8)
+    rc = L.r3d_oracle_kruskal(int(n), len(v0), order.ctypes.data_as(i64p), v0.ctypes.data_as(i64p), v1.ctypes.data_as(i64p),
+                              kept.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+    if rc < 0:
+        raise RuntimeError("kruskal oracle failed")
+    return kept.astype(bool)
+
+
+def orient_normals(points, normals, k, edges=None, delaunay_blocks_knn=True):
+    """PointCloud::OrientNormalsConsistentTangentPlane(k) (legacy; the tensor method of normal_estimation.py:21 converts
+    to legacy and calls it) [recalled, Open3D 0.17 / 0.18 with lambda = 0, cos_alpha_tol = 1]:
+      1. Delaunay tetrahedralisation; Kruskal on its edges weighted by squared length -> Euclidean MST.
+      2. Riemannian graph = EMST edges re-weighted 1 - |n_a . n_b|, plus for every point its k nearest neighbours
+         (SearchKNN: the point itself is one of the k) as edges with the same weight -- QUIRK: an edge is skipped when it
+         is already in `graph_edges`, and that set holds EVERY Delaunay edge, not only the EMST ones
+         (delaunay_blocks_knn=False adds them, i.e. what the comment in the original says it does).
+      3. Kruskal on that graph; breadth-first propagation over the tree from the point of maximum z (first one on ties),
+         whose normal is turned towards +z; a child is flipped when n_parent . n_child < 0.
+    Sign propagation over a tree does not depend on the visiting order, so the result is defined by the two spanning trees.
+    `edges` lets a test pass a precomputed Delaunay edge list (the product receives the same list)."""
+    p = np.asarray(points, np.float64)
+    nrm = np.array(normals, np.float64)
+    n = p.shape[0]
+    if n < 4:
+        raise ValueError("Not enough points to create a tetrahedral mesh.")          # TetraMesh::CreateFromPointCloud
+    de = delaunay_edges(p) if edges is None else np.asarray(edges, np.int64).reshape(-1, 2)
+    d = p[de[:, 0]] - p[de[:, 1]]
+    keep = kruskal(n, de[:, 0], de[:, 1], (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])
+    emst = de[keep]
+
+    def weight(a, b):
+        return 1.0 - np.abs((nrm[a, 0] * nrm[b, 0] + nrm[a, 1] * nrm[b, 1]) + nrm[a, 2] * nrm[b, 2])
+
+    idx, _ = _nearest_total_order(p, p, min(k, n))
+    a = np.repeat(np.arange(n, dtype=np.int64), idx.shape[1])
+    b = idx.reshape(-1).astype(np.int64)
+    sel = a != b
+    kn = np.stack([np.minimum(a[sel], b[sel]), np.maximum(a[sel], b[sel])], 1)
+    kn = np.unique(kn, axis=0)
+    blocked = de if delaunay_blocks_knn else emst
+    code = lambda e: e[:, 0] * n + e[:, 1]                                           # noqa: E731  EdgeIndex
+    kn = kn[~np.isin(code(kn), code(blocked))]
+    g = np.concatenate([emst, kn], 0)
+    tree = g[kruskal(n, g[:, 0], g[:, 1], weight(g[:, 0], g[:, 1]))]
+    # adjacency (CSR) and breadth-first propagation
+    both = np.concatenate([tree, tree[:, ::-1]], 0)
+    both = both[np.argsort(both[:, 0], kind="stable")]
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(both[:, 0], minlength=n))])
+    root = int(np.argmax(p[:, 2]))
+    if nrm[root, 2] < 0:
+        nrm[root] = -nrm[root]
+    seen = np.zeros(n, bool)
+    seen[root] = True
+    frontier = np.array([root], np.int64)
+    while frontier.size:
+        reps = ptr[frontier + 1] - ptr[frontier]
+        par = np.repeat(frontier, reps)
+        slot = np.repeat(ptr[frontier], reps) + (np.arange(int(reps.sum())) - np.repeat(np.cumsum(reps) - reps, reps))
+        child = both[slot, 1]
+        new = ~seen[child]
+        par, child = par[new], child[new]
+        flip = ((nrm[par] * nrm[child]).sum(1)) < 0
+        nrm[child[flip]] = -nrm[child[flip]]
+        seen[child] = True
+        frontier = child
+    return nrm
 
 
 # ----------------------------------------------------------------------------------------------- registration
@@ -237,7 +395,7 @@ def covariances_from_normals(normals, eps=1e-3):
 def _evaluate(src, tree, max_dist):
     """GetRegistrationResultAndCorrespondences: 1-NN with dist < max_dist; fitness, inlier RMSE (Euclidean)."""
     tgt = tree.data
-    _, cand = tree.query(src, k=min(4, tgt.shape[0]))
+    _, cand = tree.query(src, k=min(4, tgt.shape[0]), workers=-1)
     if cand.ndim == 1:
         cand = cand[:, None]
     d2 = _d2(tgt, cand, src[:, None, :])
@@ -305,3 +463,41 @@ def registration(source, target, max_dist, init=None, mode="p2p", max_iteration=
         if abs(pf - fit) < relative_fitness and abs(pr - rmse) < relative_rmse:
             break
     return dict(T=T, fitness=fit, inlier_rmse=rmse, iterations=it, correspondences=int(i.size))
+
+
+# -------------------------------------------------------------------------------------------- scanning loops
+def fuse_loop(frames, flavour="icp", threshold=0.02, voxel_size=0.01, max_iter=100, log=None):
+    """The reference's scanning loops on a list of frames (None / empty = failed capture, skipped: main.py:39,53-54).
+    flavour "icp"  -- main.py:34-54 with pointcloud_alignment.py:6-43: the first valid frame becomes the model; every later
+        frame: voxel_down_sample(voxel_size) of frame AND model, registration_icp(PointToPoint, threshold, identity,
+        criteria(1e-6, 1e-6, max_iter)), the DOWN-SAMPLED transformed frame is appended to the model.  frames: [n,3] arrays.
+    flavour "gicp" -- test/GICP1.py:134-155 with :81-104: frames are (points, normals); registration_generalized_icp
+        (threshold, identity, default criteria = 30 iterations) of the frame against the whole model, points and normals
+        transformed and appended, then estimate_normals(Hybrid(0.05, 30)) on the whole model (:148), which keeps the
+        orientation of the normals already there.
+    Returns (model points, model normals or None); `log` (list) receives one registration result per aligned frame."""
+    model = model_n = None
+    for f in frames:
+        if f is None:
+            continue
+        fp, fn = (f, None) if flavour == "icp" else f
+        if len(fp) == 0:
+            continue
+        if model is None:
+            model, model_n = np.array(fp, float), (None if fn is None else np.array(fn, float))
+            continue
+        if flavour == "icp":
+            s = voxel_down_sample(fp, voxel_size)
+            t = voxel_down_sample(model, voxel_size)
+            res = registration(s, t, threshold, mode="p2p", max_iteration=max_iter)
+            model = np.concatenate([model, transform_points(res["T"], s)], 0)
+        else:
+            res = registration(fp, model, threshold, mode="gicp", max_iteration=30, target_normals=model_n,
+                               target_cov=covariances_from_normals(model_n), source_cov=covariances_from_normals(fn))
+            T = res["T"]
+            model = np.concatenate([model, transform_points(T, fp)], 0)
+            model_n = np.concatenate([model_n, fn @ T[:3, :3].T], 0)
+            model_n = estimate_normals_hybrid(model, 0.05, 30, prev_normals=model_n)
+        if log is not None:
+            log.append(res)
+    return model, model_n

@@ -20,8 +20,8 @@ class SgbmParams(ctypes.Structure):
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "sgbm3way.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("sgbm3way.c", "graph.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
     return _SO
 

@@ -381,3 +381,148 @@ def test_degenerate_geometry_stays_finite(r3d):
     d = np.ones((50, 3))                                                          # all points coincident
     assert np.isfinite(ops.estimate_normals(d, 0.2, 20)).all()
     assert np.isfinite(ops.registration(d, d, 0.05, mode=0, max_iteration=3)["T"]).all()
+
+
+# ------------------------------------------------------------------------------- normal orientation (rows c2 / f-3)
+def _oriented_case(r3d, pts, k):
+    """Product (Qhull edges on the host, k-NN graph on the device, trees + propagation in the library) vs the oracle."""
+    n0 = co.estimate_normals_hybrid(pts, 0.05, 30)
+    edges = r3d.orientation.delaunay_edges(pts)
+    np.testing.assert_array_equal(edges, co.delaunay_edges(pts))            # same Qhull call on both sides
+    got = r3d.orientation.orient_normals_consistent_tangent_plane(pts, n0, k)
+    want = co.orient_normals(pts, n0, k)
+    return n0, got, want
+
+
+def test_orient_normals_matches_oracle_sign_for_sign(r3d):
+    """normal_estimation.py:21 orient_normals_consistent_tangent_plane(100) on a recorded frame (fp32-rounded, voxel 0.01)."""
+    pts = co.voxel_down_sample(_frame("output84", 8), 0.01).astype(np.float32).astype(np.float64)
+    n0, got, want = _oriented_case(r3d, pts, 100)
+    np.testing.assert_array_equal(got, want)                                # every sign equal, magnitudes untouched
+    np.testing.assert_array_equal(np.abs(got), np.abs(n0))
+    assert (got != n0).any(axis=1).sum() > 100                              # the propagation did flip a share of them
+    assert got[np.argmax(pts[:, 2]), 2] >= 0
+
+
+@pytest.mark.parametrize("k", [2, 12, 40])
+def test_orient_normals_oracle_parity_synthetic(r3d, k):
+    rng = np.random.default_rng(k)
+    p = _sphere(6000, 7, 0.5) + rng.normal(0, 2e-3, (6000, 3))
+    n = p / np.linalg.norm(p, axis=1, keepdims=True)
+    n = n * np.where(rng.random(len(p)) < 0.5, -1.0, 1.0)[:, None]
+    got = r3d.orientation.orient_normals_consistent_tangent_plane(p, n, k)
+    np.testing.assert_array_equal(got, co.orient_normals(p, n, k))
+    s = np.sign((got * p).sum(1))
+    assert abs(s.mean()) == 1.0 and s[np.argmax(p[:, 2])] == 1.0
+    # two far-apart sheets: the Delaunay graph keeps them connected (the k-NN-only variant roots each component itself)
+    q = np.concatenate([p, p * np.array([1.0, 1.0, 0.2]) + np.array([5.0, 0.0, -3.0])])
+    nq = np.concatenate([n, n])
+    np.testing.assert_array_equal(r3d.orientation.orient_normals_consistent_tangent_plane(q, nq, k), co.orient_normals(q, nq, k))
+    with pytest.raises(ValueError):
+        r3d.orientation.orient_normals_consistent_tangent_plane(p[:3], n[:3], k)
+    with pytest.raises(r3d.R3DError):
+        r3d.cloud_ops.orient_normals(p, n, k, delaunay_edges=np.array([[0, len(p)]]))
+
+
+def test_normal_estimation_drop_in_orientation_equals_oracle(r3d):
+    pts = co.voxel_down_sample(_frame("output84", 10), 0.01)
+    out = r3d.NormalEstimation("CUDA:0").estimate_normals(r3d.PointCloud(pts))
+    p32 = pts.astype(np.float32).astype(np.float64)
+    n_gpu_unoriented = r3d.cloud_ops.estimate_normals(p32, 0.05, 50)
+    want = co.orient_normals(p32, n_gpu_unoriented, 100)
+    np.testing.assert_array_equal(np.asarray(out.normals), want)
+    assert _sign_agnostic_err(n_gpu_unoriented, co.estimate_normals_hybrid(p32, 0.05, 50)).max() < 1e-5
+
+
+# ------------------------------------------------------------------------- tensor voxel grid / outlier stages (f-1)
+def test_tensor_voxel_downsample_matches_oracle(r3d):
+    """o3d.t voxel_down_sample on a Float32 cloud (pointcloud_processing.py:27): float32 keys from origin 0, float32 means."""
+    from PIL import Image
+    d = co.read_png16(os.path.join(GOLDEN, "output84/depth_00008.png"))
+    col = np.asarray(Image.open(os.path.join(GOLDEN, "output84/color_00008.png")))
+    pts, (v, u) = co.backproject(d, INTR)
+    c = col[v, u] / 255.0
+    for voxel in (0.02, 0.0025):
+        gp, gc, _ = r3d.cloud_ops.voxel_down_sample(pts, voxel, colors=c, tensor=True)
+        wp, wc = co.voxel_down_sample_tensor(pts, voxel, colors=c)
+        np.testing.assert_array_equal(gp, wp)
+        np.testing.assert_array_equal(gc, wc)
+        assert np.array_equal(gp, gp.astype(np.float32))                  # float32 values
+    neg = np.array([[-0.015, 0.0, 0.0], [-0.005, 0.0, 0.0], [0.005, 0.0, 0.0], [0.0049, 0.009, 0.0]])
+    np.testing.assert_array_equal(r3d.cloud_ops.voxel_down_sample(neg, 0.01, tensor=True)[0], co.voxel_down_sample_tensor(neg, 0.01))
+
+
+def test_process_point_cloud_chain_matches_oracle(r3d):
+    """pointcloud_processing.py:23-44: tensor voxel 0.0025 -> remove_statistical_outlier(30, 1.2) -> remove_radius_outlier(16, 0.01)."""
+    pts = _frame("output84", 9)
+    out = r3d.PointCloudProcessingWithCUDA("CUDA:0").process_point_cloud(r3d.PointCloud(pts))
+    w = co.voxel_down_sample_tensor(pts, 0.0025)
+    w = w[co.statistical_outlier_mask(w, 30, 1.2)]
+    w = w[co.radius_outlier_mask(w, 16, 0.01)]
+    np.testing.assert_array_equal(np.asarray(out.points), w)
+    assert 1000 < len(w) < len(pts)
+
+
+def test_statistical_outlier_with_coincident_points(r3d):
+    """>= k coincident points score 0: the original leaves them out of the mean / deviation sums and rejects them."""
+    rng = np.random.default_rng(5)
+    base = rng.random((400, 3))
+    pts = np.concatenate([base, np.repeat(base[:7], 6, axis=0)])            # 7 sites with 7 coincident points each
+    got = r3d.cloud_ops.statistical_outlier_mask(pts, 5, 1.0)
+    np.testing.assert_array_equal(got, co.statistical_outlier_mask(pts, 5, 1.0))
+    assert not got[400:].any() and not got[:7].any() and got.sum() > 100
+    assert r3d.cloud_ops.statistical_outlier_mask(np.zeros((0, 3)), 5, 1.0).shape == (0,)
+    assert r3d.cloud_ops.radius_outlier_mask(np.zeros((0, 3)), 5, 1.0).shape == (0,)
+    assert r3d.cloud_ops.estimate_normals(np.zeros((0, 3)), 0.05, 30).shape == (0, 3)
+
+
+# ------------------------------------------------------------------------------------- BASELINE config C3 at full size
+@pytest.fixture(scope="module")
+def c3(r3d):
+    src, tgt, T_star = r3d.synth.cloud_pair(1_000_000)
+    src, tgt = src.astype(np.float64), tgt.astype(np.float64)
+    sn = r3d.cloud_ops.estimate_normals(src, None, 20)
+    tn = r3d.cloud_ops.estimate_normals(tgt, None, 20)
+    return src, tgt, sn, tn, T_star
+
+
+def test_c3_knn20_normals_at_one_million_points(r3d, c3):
+    """kNN-20 PCA normals of the 1 M-point clouds (the 'no normals' branch of GICP) against the oracle on 50 000 random queries."""
+    src, tgt, sn, tn, _ = c3
+    for pts, nrm, seed in ((src, sn, 0), (tgt, tn, 1)):
+        q = np.random.default_rng(seed).choice(len(pts), 50_000, replace=False)
+        want = co.estimate_normals_knn(pts, 20, queries=q)
+        err = _sign_agnostic_err(nrm[q], want)
+        assert err.max() < 1e-6 and np.median(err) < 1e-12
+        assert np.abs(np.linalg.norm(nrm, axis=1) - 1).max() < 1e-12
+
+
+def test_c3_gicp_at_one_million_points_matches_oracle(r3d, c3):
+    """SURVEY 8d pass rule for C3: ||T - T*||_F <= 1e-3 after exactly 20 iterations, and the evaluation after 0, 1 and 2
+    updates (correspondence count, fitness, inlier RMSE, transform) equal to the CPU restatement.  Exercises the paths only a
+    cloud of this size reaches: the 144 MB dense cell table, the one-residency XCD-share grid, the outer-shell walk of the
+    unaligned first evaluation."""
+    src, tgt, sn, tn, T_star = c3
+    kw = dict(relative_fitness=-1, relative_rmse=-1, source_normals=sn, target_normals=tn)
+    res = r3d.cloud_ops.registration(src, tgt, 0.02, mode=r3d.cloud_ops.GICP, max_iteration=20, **kw)
+    assert res["iterations"] == 20 and np.linalg.norm(res["T"] - T_star) <= 1e-3
+    hist = []
+    want = co.registration(src, tgt, 0.02, mode="gicp", max_iteration=2, relative_fitness=-1, relative_rmse=-1, target_normals=tn,
+                           target_cov=co.covariances_from_normals(tn), source_cov=co.covariances_from_normals(sn), history=hist)
+    w0 = co.registration(src, tgt, 0.02, mode="gicp", max_iteration=0, target_normals=tn,
+                         target_cov=co.covariances_from_normals(tn), source_cov=co.covariances_from_normals(sn))
+    stages = [(w0["fitness"], w0["inlier_rmse"])] + hist
+    for max_it in (0, 1, 2):
+        got = r3d.cloud_ops.registration(src, tgt, 0.02, mode=r3d.cloud_ops.GICP, max_iteration=max_it, **kw)
+        fit, rmse = stages[max_it]
+        assert got["iterations"] == max_it
+        assert got["correspondences"] == round(fit * len(src))
+        assert abs(got["fitness"] - fit) < 1e-12 and abs(got["inlier_rmse"] - rmse) < 1e-9       # bar: 1e-6
+    assert got["correspondences"] == want["correspondences"]
+    assert np.abs(got["T"] - want["T"]).max() < 1e-9
+    # point-to-point and point-to-plane at full size: one update each against the oracle
+    for mode, name in ((r3d.cloud_ops.P2P, "p2p"), (r3d.cloud_ops.P2PLANE, "p2plane")):
+        g = r3d.cloud_ops.registration(src, tgt, 0.02, mode=mode, max_iteration=1, **kw)
+        w = co.registration(src, tgt, 0.02, mode=name, max_iteration=1, relative_fitness=-1, relative_rmse=-1, target_normals=tn)
+        assert g["correspondences"] == w["correspondences"] and abs(g["inlier_rmse"] - w["inlier_rmse"]) < 1e-9
+        assert np.abs(g["T"] - w["T"]).max() < 1e-9

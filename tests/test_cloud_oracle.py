@@ -129,3 +129,74 @@ def test_radius_and_statistical_masks_small_case():
     assert co.radius_outlier_mask(p, 2, 0.01).tolist() == [True, True, True, False]
     m = co.statistical_outlier_mask(np.concatenate([_sphere(300, 5, 0.05), [[3, 3, 3.0]]]), 10, 2.0)
     assert m[:-1].mean() > 0.9 and not m[-1]
+
+
+# ---- known-answer tests of the round-2 oracle additions (all PARITY UNPINNED restatements of Open3D, see the oracle header)
+def _unit_sphere(n, seed):
+    v = np.random.default_rng(seed).standard_normal((n, 3))
+    return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+
+def test_orient_normals_known_answers():
+    p = 0.5 * _unit_sphere(3000, 0)
+    rng = np.random.default_rng(1)
+    n = p / 0.5 * np.where(rng.random(len(p)) < 0.5, -1.0, 1.0)[:, None]
+    out = co.orient_normals(p, n, 10)
+    s = np.sign((out * p).sum(1))
+    assert (s == 1.0).all()                                   # closed surface, seeded upwards at the top: all outward
+    np.testing.assert_array_equal(np.abs(out), np.abs(n))
+    # the spanning trees are unique here (no equal weights), so the propagation is independent of the blocking quirk's
+    # visiting order but not of the graph: both variants must still give a consistent orientation
+    alt = co.orient_normals(p, n, 10, delaunay_blocks_knn=False)
+    assert abs(np.sign((alt * p).sum(1)).mean()) == 1.0
+    # Kruskal: a triangle with one heavy edge keeps the two light ones
+    keep = co.kruskal(3, np.array([0, 1, 0]), np.array([1, 2, 2]), np.array([1.0, 2.0, 3.0]))
+    assert keep.tolist() == [True, True, False]
+    # ties are visited in (v0, v1) order
+    keep = co.kruskal(3, np.array([0, 0, 1]), np.array([2, 1, 2]), np.array([1.0, 1.0, 1.0]))
+    assert keep.tolist() == [True, True, False]
+    with pytest.raises(ValueError):
+        co.orient_normals(p[:3], n[:3], 2)
+
+
+def test_delaunay_edges_of_a_cube_corner_set():
+    p = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [0.2, 0.2, 0.2]], float)
+    e = co.delaunay_edges(p)
+    assert len(e) == 10 and (e[:, 0] < e[:, 1]).all()         # the inner point sees every corner: complete graph K5
+
+
+def test_tensor_voxel_grid_known_answers():
+    pts = np.array([[-0.015, 0, 0], [-0.005, 0, 0], [0.005, 0, 0], [0.0049, 0.0099, 0]])
+    out = co.voxel_down_sample_tensor(pts, 0.01)
+    # keys floor(p / 0.01): (-2,0,0), (-1,0,0), (0,0,0) x 2 -> three voxels, lexicographic key order
+    assert out.shape == (3, 3)
+    f = np.float32
+    assert out[2, 0] == float((f(0.005) + f(0.0049)) / f(2)) and out[0, 0] == float(f(-0.015))
+    # legacy grid (origin min - voxel/2) partitions the same points differently
+    assert co.voxel_down_sample(pts, 0.01).shape[0] == 4
+
+
+def test_statistical_outlier_rule_with_coincident_points():
+    rng = np.random.default_rng(5)
+    base = rng.random((300, 3))
+    pts = np.concatenate([base, np.repeat(base[:5], 4, axis=0)])
+    m = co.statistical_outlier_mask(pts, 4, 1.0)
+    assert not m[300:].any() and not m[:5].any()              # score 0 (>= k coincident points): rejected
+    plain = co.statistical_outlier_mask(base, 4, 1.0)
+    d = np.sort(np.linalg.norm(base[:, None] - base[None], axis=2), 1)[:, :4].mean(1)
+    np.testing.assert_array_equal(plain, d < d.mean() + d.std(ddof=1))
+
+
+def test_fuse_loop_small():
+    a = 0.3 * _unit_sphere(1500, 3) * np.array([1.0, 0.7, 0.5])
+    c, s = np.cos(0.01), np.sin(0.01)
+    T = np.array([[c, -s, 0, 0.002], [s, c, 0, -0.001], [0, 0, 1, 0.0015], [0, 0, 0, 1.0]])
+    b = co.transform_points(np.linalg.inv(T), a)
+    log = []
+    model, _ = co.fuse_loop([None, a, np.zeros((0, 3)), b], "icp", threshold=0.02, voxel_size=0.004, log=log)
+    assert len(log) == 1 and len(model) == len(a) + len(co.voxel_down_sample(b, 0.004))
+    na, nb = co.estimate_normals_knn(a, 12), co.estimate_normals_knn(b, 12)
+    log = []
+    model, mn = co.fuse_loop([(a, na), (b, nb)], "gicp", log=log)
+    assert model.shape == (3000, 3) and mn.shape == (3000, 3) and np.abs(log[0]["T"] - T).max() < 1e-3
+    assert ((mn[:1500] * na).sum(1) > 0).all()                # re-estimated normals keep the orientation already there

@@ -31,22 +31,41 @@ def test_reproject_disparity_matches_formula(r3d):
     assert empty.shape == (0, 3)
 
 
-def test_fuse_loop_matches_oracle_on_fixture_frames(r3d):
-    """main.py:34-54 on recorded frames 8..11 (config C4, shortened): first frame initialises the model, later frames
-    are aligned to the growing model with align_point_clouds(threshold=0.02, voxel_size=0.01, max_iter=100)."""
+def _c4_frames():
+    return [co.backproject(co.read_png16(os.path.join(GOLDEN, f"output84/depth_{i:05d}.png")), INTR)[0] for i in range(8, 16)]
+
+
+def test_fuse_loop_icp_flavour_all_eight_c4_frames(r3d):
+    """BASELINE config C4, main.py:34-54 flavour: recorded frames 8..15 (voxel 0.01), first frame initialises the model, every
+    later frame is aligned to the growing model with align_point_clouds(threshold=0.02, voxel_size=0.01, max_iter=100)
+    (pointcloud_alignment.py:6-43) and its down-sampled transformed copy is appended; failed captures are skipped."""
+    frames = [co.voxel_down_sample(f, 0.01) for f in _c4_frames()]
+    feed = [r3d.PointCloud(f) for f in frames]
+    feed[3:3] = [None, r3d.PointCloud()]                                # main.py:39,53-54: skipped
+    got = r3d.pipeline.fuse(feed, flavour="icp")
+    log = []
+    want, _ = co.fuse_loop(frames, "icp", threshold=0.02, voxel_size=0.01, max_iter=100, log=log)
+    assert got.points.shape == want.shape and len(log) == 7
+    assert np.abs(got.points - want).max() < 1e-6                      # bar (north_star): 1e-3 on coordinates
+
+
+def test_fuse_loop_gicp_flavour_all_eight_c4_frames(r3d):
+    """BASELINE config C4, test/GICP1.py:134-155 flavour: frames are tensor-voxel-down-sampled (:71-72) and carry
+    Hybrid(0.05, 30) normals (:77); every later frame is registered to the WHOLE model with registration_generalized_icp
+    (:99-102), appended with its normals, and the model's normals are re-estimated (:148) keeping their orientation."""
     frames = []
-    for i in (8, 9, 10, 11):
-        d = co.read_png16(os.path.join(GOLDEN, f"output84/depth_{i:05d}.png"))
-        frames.append(co.voxel_down_sample(co.backproject(d, INTR)[0], 0.01))
-    got = r3d.pipeline.fuse([r3d.PointCloud(f) for f in frames] + [None, r3d.PointCloud()], flavour="icp")
-    model = frames[0]
-    for f in frames[1:]:
-        s = co.voxel_down_sample(f, 0.01)
-        t = co.voxel_down_sample(model, 0.01)
-        T = co.registration(s, t, 0.02, mode="p2p", max_iteration=100)["T"]
-        model = np.concatenate([model, co.transform_points(T, s)], 0)
-    assert got.points.shape == model.shape
-    assert np.abs(got.points - model).max() < 1e-6                     # bar: 1e-3
+    for f in _c4_frames():
+        p = co.voxel_down_sample_tensor(f, 0.01)
+        frames.append((p, co.estimate_normals_hybrid(p, 0.05, 30)))
+    got = r3d.pipeline.fuse([r3d.PointCloud(p, normals=n) for p, n in frames], flavour="gicp")
+    log = []
+    want_p, want_n = co.fuse_loop(frames, "gicp", threshold=0.02, log=log)
+    assert got.points.shape == want_p.shape and got.has_normals() and len(log) == 7
+    assert np.abs(got.points - want_p).max() < 1e-6                    # bar: 1e-3
+    # normals: 1e-3 bar; a normal whose two smallest eigenvalues nearly coincide amplifies the 1e-9 coordinate differences,
+    # so the bound is stated on all points at the bar and on the bulk far below it
+    err = np.abs(got.normals - want_n).max(1)
+    assert err.max() < 1e-3 and np.quantile(err, 0.999) < 1e-6
 
 
 def test_view_to_cloud_and_single_rank_multi_view(r3d, synth):
