@@ -42,6 +42,27 @@ _lib.register({
 })
 
 
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_lib.register({
+    "r3d_model_create": ([_vp, ctypes.POINTER(_vp)], ctypes.c_int),
+    "r3d_model_destroy": ([_vp], None),
+    "r3d_model_clear": ([_vp], ctypes.c_int),
+    "r3d_model_size": ([_vp, _i64p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)], ctypes.c_int),
+    "r3d_model_append": ([_vp, _vp, _vp, _vp, ctypes.c_int64], ctypes.c_int),
+    "r3d_model_align_append": ([_vp, ctypes.POINTER(AlignParams), _vp, _vp, ctypes.c_int64, _vp, ctypes.POINTER(_lib.IcpStats), _i64p],
+                               ctypes.c_int),
+    "r3d_model_register_append": ([_vp, ctypes.POINTER(_lib.IcpParams), _vp, _vp, _vp, ctypes.c_int64, _vp,
+                                   ctypes.POINTER(_lib.IcpStats)], ctypes.c_int),
+    "r3d_model_estimate_normals": ([_vp, ctypes.c_double, ctypes.c_int32], ctypes.c_int),
+    "r3d_model_download": ([_vp, _vp, _vp, _vp], ctypes.c_int),
+    "r3d_disparity_to_cloud_resident": ([_vp, _vp, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_int32, ctypes.c_double, _vp,
+                                         ctypes.c_double, ctypes.c_double, ctypes.c_int32, ctypes.c_int64, _vp, _vp, _i64p], ctypes.c_int),
+    "r3d_icp_dev": ([_vp, ctypes.POINTER(_lib.IcpParams), _vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp,
+                     ctypes.POINTER(_lib.IcpStats)], ctypes.c_int),
+    "r3d_transform_points_dev": ([_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int32, _vp], ctypes.c_int),
+})
+
+
 def _c(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 3)
 
@@ -190,9 +211,7 @@ def registration(source, target, max_correspondence_distance, init=None, mode=P2
     st = _lib.IcpStats()
     ctx.call("r3d_icp", ctypes.byref(prm), _ptr(s), len(s), _ptr(sn), _ptr(t), len(t), _ptr(tn), _ptr(T0), _ptr(T),
              ctypes.byref(st))
-    return dict(T=T, fitness=st.fitness, inlier_rmse=st.inlier_rmse, iterations=st.iterations,
-                converged=bool(st.converged), correspondences=st.correspondences, setup_ms=st.setup_ms,
-                loop_ms=st.loop_ms)
+    return _stats_dict(T, st)
 
 
 def align_point_clouds(source, target, threshold=0.02, voxel_size=0.01, max_iteration=100, mode=P2P, normal_radius=None,
@@ -221,3 +240,122 @@ def align_point_clouds(source, target, threshold=0.02, voxel_size=0.01, max_iter
     return dict(points=op[:m].copy(), colors=None if oc is None else oc[:m].copy(), normals=None if on is None else on[:m].copy(),
                 T=T, fitness=st.fitness, inlier_rmse=st.inlier_rmse, iterations=st.iterations, converged=bool(st.converged),
                 correspondences=st.correspondences, setup_ms=st.setup_ms, loop_ms=st.loop_ms)
+
+
+def _stats_dict(T, st):
+    return dict(T=T, fitness=st.fitness, inlier_rmse=st.inlier_rmse, iterations=st.iterations, converged=bool(st.converged),
+                correspondences=st.correspondences, setup_ms=st.setup_ms, loop_ms=st.loop_ms)
+
+
+class ResidentModel:
+    """The growing `combined_pcd` of the scanning loops (main.py:28,34-54; test/GICP1.py:134-155) kept in HBM (r3d_model_*):
+    per frame only the frame is uploaded and the 4x4 + statistics come back; download() fetches the model once at the end."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or _lib.default_context()
+        h = _vp()
+        self.ctx.check(self.ctx._lib.r3d_model_create(self.ctx._h, ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            self.ctx._lib.r3d_model_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _call(self, name, *args):
+        self.ctx.check(getattr(self.ctx._lib, name)(self._h, *args))
+
+    def size(self):
+        n, hc, hn = ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32()
+        self._call("r3d_model_size", ctypes.byref(n), ctypes.byref(hc), ctypes.byref(hn))
+        return n.value, bool(hc.value), bool(hn.value)
+
+    def __len__(self):
+        return self.size()[0]
+
+    def clear(self):
+        self._call("r3d_model_clear")
+
+    def append(self, points, colors=None, normals=None):
+        p, c, n = _c(points), _c(colors), _c(normals)
+        self._call("r3d_model_append", _ptr(p), _ptr(c), _ptr(n), len(p))
+
+    def align_append(self, source, threshold=0.02, voxel_size=0.01, max_iteration=100, mode=P2P, normal_radius=None,
+                     normal_max_nn=30, source_colors=None, relative_fitness=1e-6, relative_rmse=1e-6, gicp_epsilon=1e-3):
+        """align_point_clouds(frame, model, threshold, voxel_size, max_iter) followed by model += aligned (main.py:48-49)."""
+        s, sc = _c(source), _c(source_colors)
+        prm = AlignParams(_lib.IcpParams(int(mode), int(max_iteration), float(threshold), float(relative_fitness),
+                                         float(relative_rmse), float(gicp_epsilon)),
+                          float(voxel_size) if voxel_size else -1.0,
+                          float(normal_radius) if normal_radius else (2.0 * voxel_size if voxel_size else -1.0),
+                          int(normal_max_nn) if normal_max_nn else 0, 0)
+        T = np.empty((4, 4))
+        st = _lib.IcpStats()
+        m = ctypes.c_int64()
+        self._call("r3d_model_align_append", ctypes.byref(prm), _ptr(s), _ptr(sc), len(s), _ptr(T), ctypes.byref(st), ctypes.byref(m))
+        return dict(_stats_dict(T, st), appended=m.value)
+
+    def register_append(self, source, threshold=0.02, mode=GICP, max_iteration=30, source_colors=None, source_normals=None,
+                        relative_fitness=1e-6, relative_rmse=1e-6, gicp_epsilon=1e-3):
+        """registration of the frame against the whole model, then model += transformed frame (test/GICP1.py:145-146)."""
+        s, sc, sn = _c(source), _c(source_colors), _c(source_normals)
+        prm = _lib.IcpParams(int(mode), int(max_iteration), float(threshold), float(relative_fitness), float(relative_rmse),
+                             float(gicp_epsilon))
+        T = np.empty((4, 4))
+        st = _lib.IcpStats()
+        self._call("r3d_model_register_append", ctypes.byref(prm), _ptr(s), _ptr(sc), _ptr(sn), len(s), _ptr(T), ctypes.byref(st))
+        return _stats_dict(T, st)
+
+    def estimate_normals(self, radius=0.05, max_nn=30):
+        self._call("r3d_model_estimate_normals", float(radius) if radius else -1.0, int(max_nn))
+
+    def download(self):
+        n, hc, hn = self.size()
+        p = np.empty((n, 3))
+        c = np.empty((n, 3)) if hc else None
+        nr = np.empty((n, 3)) if hn else None
+        if n:
+            self._call("r3d_model_download", _ptr(p), _ptr(c), _ptr(nr))
+        return p, c, nr
+
+
+def disparity_to_cloud_resident(d_disp, width, height, Q, d_out_points, d_out_normals, capacity, min_disparity=0, max_depth=None,
+                                pose=None, voxel=0.01, normal_radius=None, max_nn=30, ctx=None):
+    """r3d_disparity_to_cloud_resident: like disparity_to_cloud_device, but the cloud is written to the caller's DEVICE buffers
+    (pointers as ints, `capacity` triplets each; e.g. torch tensors' data_ptr()).  Returns the number of points."""
+    ctx = ctx or _lib.default_context()
+    Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(4, 4)
+    P = None if pose is None else np.ascontiguousarray(pose, dtype=np.float64).reshape(4, 4)
+    m = ctypes.c_int64()
+    ctx.call("r3d_disparity_to_cloud_resident", _vp(d_disp), int(width), int(height), _ptr(Q), int(min_disparity) * 16,
+             float(max_depth) if max_depth else -1.0, _ptr(P), float(voxel) if voxel else -1.0,
+             float(normal_radius) if normal_radius else -1.0, int(max_nn) if max_nn else 0, int(capacity), _vp(d_out_points),
+             _vp(d_out_normals) if d_out_normals else None, ctypes.byref(m))
+    return m.value
+
+
+def registration_device(d_source, ns, d_target, nt, max_correspondence_distance, init=None, mode=P2P, max_iteration=30,
+                        relative_fitness=1e-6, relative_rmse=1e-6, d_source_normals=None, d_target_normals=None, gicp_epsilon=1e-3,
+                        ctx=None):
+    """r3d_icp_dev: registration of two clouds that are already in HBM (device pointers as ints)."""
+    ctx = ctx or _lib.default_context()
+    T0 = None if init is None else np.ascontiguousarray(init, dtype=np.float64).reshape(4, 4)
+    T = np.empty((4, 4))
+    prm = _lib.IcpParams(int(mode), int(max_iteration), float(max_correspondence_distance), float(relative_fitness),
+                         float(relative_rmse), float(gicp_epsilon))
+    st = _lib.IcpStats()
+    ctx.call("r3d_icp_dev", ctypes.byref(prm), _vp(d_source), int(ns), _vp(d_source_normals) if d_source_normals else None,
+             _vp(d_target), int(nt), _vp(d_target_normals) if d_target_normals else None, _ptr(T0), _ptr(T), ctypes.byref(st))
+    return _stats_dict(T, st)
+
+
+def transform_points_device(d_points, n, T, d_out, rotate_only=False, ctx=None):
+    ctx = ctx or _lib.default_context()
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(4, 4)
+    ctx.call("r3d_transform_points_dev", _vp(d_points), int(n), _ptr(T), int(bool(rotate_only)), _vp(d_out))

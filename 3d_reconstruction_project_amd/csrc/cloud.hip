@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -1909,9 +1910,9 @@ int r3d_reproject_disparity(r3d_ctx *ctx, const int16_t *disp, int32_t w, int32_
     return R3D_OK;
 }
 
-int r3d_disparity_to_cloud_dev(r3d_ctx *ctx, const int16_t *d_disp, int32_t w, int32_t h, const double *Q4x4, int32_t min_valid_x16,
-                               double max_depth, const double *pose4x4, double voxel, double normal_radius, int32_t max_nn,
-                               int64_t capacity, double *out_xyz, double *out_normals, int64_t *out_n) {
+static int disparity_to_cloud_impl(r3d_ctx *ctx, const int16_t *d_disp, int32_t w, int32_t h, const double *Q4x4, int32_t min_valid_x16,
+                                   double max_depth, const double *pose4x4, double voxel, double normal_radius, int32_t max_nn,
+                                   int64_t capacity, double *out_xyz, double *out_normals, int64_t *out_n, bool device_out) {
     if (!ctx) return R3D_E_BADARG;
     if (!d_disp || !Q4x4 || !out_xyz || !out_n || w <= 0 || h <= 0 || capacity < 0)
         return r3d_fail(ctx, R3D_E_BADARG, "disparity_to_cloud: bad argument");
@@ -1947,10 +1948,27 @@ int r3d_disparity_to_cloud_dev(r3d_ctx *ctx, const int16_t *d_disp, int32_t w, i
     if (m > capacity) return r3d_fail(ctx, R3D_E_BADARG, "disparity_to_cloud: %lld points, output arrays hold %lld", (long long)m, (long long)capacity);
     double *d_n = nullptr;
     if (max_nn > 0 && (rc = normals_core(ctx, ar, d_p, m, normal_radius, max_nn, nullptr, &d_n))) return rc;
-    R3D_HIP(ctx, hipMemcpyAsync(out_xyz, d_p, (size_t)m * 24, hipMemcpyDeviceToHost, ctx->stream));
-    if (d_n) R3D_HIP(ctx, hipMemcpyAsync(out_normals, d_n, (size_t)m * 24, hipMemcpyDeviceToHost, ctx->stream));
-    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const hipMemcpyKind kind = device_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    R3D_HIP(ctx, hipMemcpyAsync(out_xyz, d_p, (size_t)m * 24, kind, ctx->stream));
+    if (d_n) R3D_HIP(ctx, hipMemcpyAsync(out_normals, d_n, (size_t)m * 24, kind, ctx->stream));
+    // device outputs stay ordered on the context stream (the caller's next kernel or collective on that stream sees them);
+    // the arena is only reused by later calls on the same stream, so no wait is needed here either
+    if (!device_out) R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return R3D_OK;
+}
+
+int r3d_disparity_to_cloud_dev(r3d_ctx *ctx, const int16_t *d_disp, int32_t w, int32_t h, const double *Q4x4, int32_t min_valid_x16,
+                               double max_depth, const double *pose4x4, double voxel, double normal_radius, int32_t max_nn,
+                               int64_t capacity, double *out_xyz, double *out_normals, int64_t *out_n) {
+    return disparity_to_cloud_impl(ctx, d_disp, w, h, Q4x4, min_valid_x16, max_depth, pose4x4, voxel, normal_radius, max_nn, capacity,
+                                   out_xyz, out_normals, out_n, false);
+}
+
+int r3d_disparity_to_cloud_resident(r3d_ctx *ctx, const int16_t *d_disp, int32_t w, int32_t h, const double *Q4x4, int32_t min_valid_x16,
+                                    double max_depth, const double *pose4x4, double voxel, double normal_radius, int32_t max_nn,
+                                    int64_t capacity, double *d_out_xyz, double *d_out_normals, int64_t *out_n) {
+    return disparity_to_cloud_impl(ctx, d_disp, w, h, Q4x4, min_valid_x16, max_depth, pose4x4, voxel, normal_radius, max_nn, capacity,
+                                   d_out_xyz, d_out_normals, out_n, true);
 }
 
 int r3d_align_point_clouds(r3d_ctx *ctx, const r3d_align_params *p, const double *src, const double *src_colors, int64_t ns,
@@ -2224,6 +2242,255 @@ int r3d_icp(r3d_ctx *ctx, const r3d_icp_params *p, const double *src, int64_t ns
     if (src_normals && (rc = upload(ctx, ar, src_normals, ns * 3, &d_sn))) return rc;
     if (tgt_normals && (rc = upload(ctx, ar, tgt_normals, nt * 3, &d_tn))) return rc;
     return icp_core(ctx, ar, p, d_s, ns, d_sn, d_t, nt, d_tn, init4x4, T4x4, stats, t_begin);
+}
+
+// ---- resident scan-loop model (main.py:34-54, test/GICP1.py:134-155) ---------------------------------
+// The reference keeps the growing model in an Open3D cloud and hands ALL of it to align_point_clouds for every frame, which
+// voxel-down-samples it again (pointcloud_alignment.py:22-23).  Here the model's points / colours / normals live in device
+// buffers owned by an r3d_model: a frame goes up, the 4x4 and the statistics come down, nothing else crosses PCIe until
+// r3d_model_download.  Every step runs the same kernels in the same order as the one-shot entry points on the same values
+// (the model is re-voxelised from its resident points, in their original order), so the results are identical to them.
+}  // extern "C"
+struct r3d_model {
+    r3d_ctx *ctx = nullptr;
+    r3d_buf pts, cols, nrms;
+    int64_t n = 0;
+    bool has_colors = false, has_normals = false;
+};
+namespace {
+// grows a model buffer to hold `rows` triplets, keeping the first `keep` rows
+int model_reserve(r3d_model *m, r3d_buf &b, int64_t rows, int64_t keep) {
+    r3d_ctx *ctx = m->ctx;
+    const size_t bytes = (size_t)rows * 24;
+    if (bytes <= b.cap) return R3D_OK;
+    const size_t want = bytes + bytes / 2 + 4096;
+    void *np = nullptr;
+    hipError_t e = hipMalloc(&np, want);
+    if (e != hipSuccess) return r3d_fail(ctx, R3D_E_OOM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    if (b.p && keep > 0) {
+        e = hipMemcpyAsync(np, b.p, (size_t)keep * 24, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e != hipSuccess) { (void)hipFree(np); return r3d_fail(ctx, R3D_E_HIP, "model grow copy failed: %s", hipGetErrorString(e)); }
+    }
+    if (b.p) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(b.p);
+    }
+    b.p = np;
+    b.cap = want;
+    return R3D_OK;
+}
+// appends n rows (device or host source) with the attribute rule of the legacy operator+= (an attribute survives only when
+// the model is empty or already carries it AND the appended cloud carries it)
+int model_append(r3d_model *m, const double *xyz, const double *colors, const double *normals, int64_t n, hipMemcpyKind kind) {
+    r3d_ctx *ctx = m->ctx;
+    const bool keep_c = (m->n == 0 || m->has_colors) && colors, keep_n = (m->n == 0 || m->has_normals) && normals;
+    int rc;
+    if ((rc = model_reserve(m, m->pts, m->n + n, m->n))) return rc;
+    if (keep_c && (rc = model_reserve(m, m->cols, m->n + n, m->n))) return rc;
+    if (keep_n && (rc = model_reserve(m, m->nrms, m->n + n, m->n))) return rc;
+    R3D_HIP(ctx, hipMemcpyAsync((double *)m->pts.p + m->n * 3, xyz, (size_t)n * 24, kind, ctx->stream));
+    if (keep_c) R3D_HIP(ctx, hipMemcpyAsync((double *)m->cols.p + m->n * 3, colors, (size_t)n * 24, kind, ctx->stream));
+    if (keep_n) R3D_HIP(ctx, hipMemcpyAsync((double *)m->nrms.p + m->n * 3, normals, (size_t)n * 24, kind, ctx->stream));
+    if (kind == hipMemcpyHostToDevice) R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the caller may reuse its arrays
+    m->has_colors = keep_c;
+    m->has_normals = keep_n;
+    m->n += n;
+    return R3D_OK;
+}
+}  // namespace
+extern "C" {
+
+int r3d_model_create(r3d_ctx *ctx, r3d_model **out) {
+    if (!ctx || !out) return R3D_E_BADARG;
+    r3d_model *m = new (std::nothrow) r3d_model;
+    if (!m) return r3d_fail(ctx, R3D_E_OOM, "model_create: out of host memory");
+    m->ctx = ctx;
+    *out = m;
+    return R3D_OK;
+}
+
+void r3d_model_destroy(r3d_model *m) {
+    if (!m) return;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    for (r3d_buf *b : {&m->pts, &m->cols, &m->nrms})
+        if (b->p) (void)hipFree(b->p);
+    delete m;
+}
+
+int r3d_model_clear(r3d_model *m) {
+    if (!m) return R3D_E_BADARG;
+    m->n = 0;
+    m->has_colors = m->has_normals = false;
+    return R3D_OK;
+}
+
+int r3d_model_size(r3d_model *m, int64_t *n, int32_t *has_colors, int32_t *has_normals) {
+    if (!m) return R3D_E_BADARG;
+    if (n) *n = m->n;
+    if (has_colors) *has_colors = m->has_colors;
+    if (has_normals) *has_normals = m->has_normals;
+    return R3D_OK;
+}
+
+int r3d_model_append(r3d_model *m, const double *xyz, const double *colors, const double *normals, int64_t n) {
+    if (!m) return R3D_E_BADARG;
+    r3d_ctx *ctx = m->ctx;
+    if (!xyz || n < 0) return r3d_fail(ctx, R3D_E_BADARG, "model_append: bad argument");
+    if (n == 0) return R3D_OK;
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    return model_append(m, xyz, colors, normals, n, hipMemcpyHostToDevice);
+}
+
+int r3d_model_align_append(r3d_model *m, const r3d_align_params *p, const double *src, const double *src_colors, int64_t ns,
+                           double *T4x4, r3d_icp_stats *stats, int64_t *appended) {
+    if (!m) return R3D_E_BADARG;
+    r3d_ctx *ctx = m->ctx;
+    if (!p || !src || !T4x4 || ns <= 0) return r3d_fail(ctx, R3D_E_BADARG, "model_align_append: bad argument");
+    if (m->n <= 0) return r3d_fail(ctx, R3D_E_BADARG, "model_align_append: the model is empty (append the first frame)");
+    const r3d_icp_params *ip = &p->icp;
+    if (ip->mode < 0 || ip->mode > 2) return r3d_fail(ctx, R3D_E_BADARG, "model_align_append: mode must be 0 (P2P), 1 (P2PLANE) or 2 (GICP)");
+    if (!(ip->max_correspondence_distance > 0)) return r3d_fail(ctx, R3D_E_BADARG, "model_align_append: max_correspondence_distance must be > 0");
+    if (p->normal_max_nn > 128) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "model_align_append: normal_max_nn > 128 not supported");
+    if (ip->mode != MODE_P2P && p->normal_max_nn <= 0) return r3d_fail(ctx, R3D_E_BADARG, "model_align_append: this mode needs normals (normal_max_nn > 0)");
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    const auto t_begin = std::chrono::steady_clock::now();
+    DevArena ar(ctx);
+    int rc;
+    double *d_s, *d_c = nullptr, *d_t = (double *)m->pts.p;
+    if ((rc = upload(ctx, ar, src, ns * 3, &d_s))) return rc;
+    if (src_colors && (rc = upload(ctx, ar, src_colors, ns * 3, &d_c))) return rc;
+    int64_t ms = ns, mt = m->n;
+    if (p->voxel_size > 0) {  // pointcloud_alignment.py:22-23 on the frame and on the WHOLE resident model
+        VoxelSegs V;
+        if ((rc = voxel_segments(ctx, ar, d_s, ns, p->voxel_size, V))) return rc;
+        double *d_sv = (double *)ar.get((size_t)V.nseg * 24), *d_cv = d_c ? (double *)ar.get((size_t)V.nseg * 24) : nullptr;
+        if (ar.rc) return ar.rc;
+        k_voxel_mean<<<(unsigned)((V.nseg + 255) / 256), 256, 0, ctx->stream>>>(d_s, V.idx, V.starts, V.nseg, ns, d_sv);
+        if (d_c) k_voxel_mean<<<(unsigned)((V.nseg + 255) / 256), 256, 0, ctx->stream>>>(d_c, V.idx, V.starts, V.nseg, ns, d_cv);
+        R3D_HIP(ctx, hipGetLastError());
+        d_s = d_sv;
+        d_c = d_cv;
+        ms = V.nseg;
+        VoxelSegs Vt;
+        if ((rc = voxel_segments(ctx, ar, d_t, m->n, p->voxel_size, Vt))) return rc;
+        double *d_tv = (double *)ar.get((size_t)Vt.nseg * 24);
+        if (ar.rc) return ar.rc;
+        k_voxel_mean<<<(unsigned)((Vt.nseg + 255) / 256), 256, 0, ctx->stream>>>(d_t, Vt.idx, Vt.starts, Vt.nseg, m->n, d_tv);
+        R3D_HIP(ctx, hipGetLastError());
+        d_t = d_tv;
+        mt = Vt.nseg;
+    }
+    // pointcloud_alignment.py:27-28 estimates normals on both clouds.  The point-to-point estimator never reads them and the
+    // model's operator+= drops the frame's normals unless the model carries normals itself, so they are computed only where
+    // they can reach a result: target normals for the plane / GICP estimators, source normals for GICP or a model with normals.
+    double *d_sn = nullptr, *d_tn = nullptr;
+    const bool want_sn = p->normal_max_nn > 0 && (ip->mode == MODE_GICP || m->has_normals);
+    if (want_sn && (rc = normals_core(ctx, ar, d_s, ms, p->normal_radius, p->normal_max_nn, nullptr, &d_sn))) return rc;
+    if (ip->mode != MODE_P2P && (rc = normals_core(ctx, ar, d_t, mt, p->normal_radius, p->normal_max_nn, nullptr, &d_tn))) return rc;
+    double T[16];
+    if ((rc = icp_core(ctx, ar, ip, d_s, ms, d_sn, d_t, mt, d_tn, nullptr, T, stats, t_begin))) return rc;  // :35-39, from identity
+    memcpy(T4x4, T, sizeof T);
+    double *d_o = (double *)ar.get((size_t)ms * 24), *d_on = d_sn ? (double *)ar.get((size_t)ms * 24) : nullptr;
+    if (ar.rc) return ar.rc;
+    const unsigned nb = (unsigned)((ms + 255) / 256);
+    k_transform<<<nb, 256, 0, ctx->stream>>>(d_s, ms, to_rigid(T), 0, d_o);  // :42 source.transform
+    if (d_sn) k_transform<<<nb, 256, 0, ctx->stream>>>(d_sn, ms, to_rigid(T), 1, d_on);
+    R3D_HIP(ctx, hipGetLastError());
+    if ((rc = model_append(m, d_o, d_c, d_on, ms, hipMemcpyDeviceToDevice))) return rc;   // main.py:49 combined += aligned
+    if (appended) *appended = ms;
+    return R3D_OK;
+}
+
+int r3d_model_register_append(r3d_model *m, const r3d_icp_params *p, const double *src, const double *src_colors, const double *src_normals,
+                              int64_t ns, double *T4x4, r3d_icp_stats *stats) {
+    if (!m) return R3D_E_BADARG;
+    r3d_ctx *ctx = m->ctx;
+    if (!p || !src || !T4x4 || ns <= 0) return r3d_fail(ctx, R3D_E_BADARG, "model_register_append: bad argument");
+    if (m->n <= 0) return r3d_fail(ctx, R3D_E_BADARG, "model_register_append: the model is empty (append the first frame)");
+    if (p->mode < 0 || p->mode > 2) return r3d_fail(ctx, R3D_E_BADARG, "model_register_append: mode must be 0 (P2P), 1 (P2PLANE) or 2 (GICP)");
+    if (!(p->max_correspondence_distance > 0)) return r3d_fail(ctx, R3D_E_BADARG, "model_register_append: max_correspondence_distance must be > 0");
+    if (p->mode != MODE_P2P && !m->has_normals) return r3d_fail(ctx, R3D_E_BADARG, "model_register_append: the model has no normals (r3d_model_estimate_normals)");
+    if (p->mode == MODE_GICP && !src_normals) return r3d_fail(ctx, R3D_E_BADARG, "model_register_append: source normals required for GICP");
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    const auto t_begin = std::chrono::steady_clock::now();
+    DevArena ar(ctx);
+    int rc;
+    double *d_s, *d_c = nullptr, *d_sn = nullptr;
+    if ((rc = upload(ctx, ar, src, ns * 3, &d_s))) return rc;
+    if (src_colors && (rc = upload(ctx, ar, src_colors, ns * 3, &d_c))) return rc;
+    if (src_normals && (rc = upload(ctx, ar, src_normals, ns * 3, &d_sn))) return rc;
+    double T[16];
+    if ((rc = icp_core(ctx, ar, p, d_s, ns, d_sn, (double *)m->pts.p, m->n, m->has_normals ? (double *)m->nrms.p : nullptr, nullptr, T, stats, t_begin)))
+        return rc;                                                                     // test/GICP1.py:99-102, from identity
+    memcpy(T4x4, T, sizeof T);
+    double *d_o = (double *)ar.get((size_t)ns * 24), *d_on = d_sn ? (double *)ar.get((size_t)ns * 24) : nullptr;
+    if (ar.rc) return ar.rc;
+    const unsigned nb = (unsigned)((ns + 255) / 256);
+    k_transform<<<nb, 256, 0, ctx->stream>>>(d_s, ns, to_rigid(T), 0, d_o);            // :103 source.transform
+    if (d_sn) k_transform<<<nb, 256, 0, ctx->stream>>>(d_sn, ns, to_rigid(T), 1, d_on);
+    R3D_HIP(ctx, hipGetLastError());
+    return model_append(m, d_o, d_c, d_on, ns, hipMemcpyDeviceToDevice);               // :146 combined += aligned
+}
+
+int r3d_model_estimate_normals(r3d_model *m, double radius, int32_t max_nn) {
+    if (!m) return R3D_E_BADARG;
+    r3d_ctx *ctx = m->ctx;
+    if (max_nn < 1) return r3d_fail(ctx, R3D_E_BADARG, "model_estimate_normals: bad argument");
+    if (max_nn > 128) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "model_estimate_normals: max_nn > 128 not supported");
+    if (m->n == 0) return R3D_OK;
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    DevArena ar(ctx);
+    int rc;
+    double *d_n;
+    // legacy EstimateNormals on a cloud that already has normals keeps their orientation (test/GICP1.py:148)
+    if ((rc = normals_core(ctx, ar, (double *)m->pts.p, m->n, radius, max_nn, m->has_normals ? (double *)m->nrms.p : nullptr, &d_n))) return rc;
+    if ((rc = model_reserve(m, m->nrms, m->n, m->has_normals ? m->n : 0))) return rc;
+    R3D_HIP(ctx, hipMemcpyAsync(m->nrms.p, d_n, (size_t)m->n * 24, hipMemcpyDeviceToDevice, ctx->stream));
+    m->has_normals = true;
+    return R3D_OK;
+}
+
+int r3d_model_download(r3d_model *m, double *xyz, double *colors, double *normals) {
+    if (!m) return R3D_E_BADARG;
+    r3d_ctx *ctx = m->ctx;
+    if (!xyz) return r3d_fail(ctx, R3D_E_BADARG, "model_download: bad argument");
+    if (m->n == 0) return R3D_OK;
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    R3D_HIP(ctx, hipMemcpyAsync(xyz, m->pts.p, (size_t)m->n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    if (colors && m->has_colors) R3D_HIP(ctx, hipMemcpyAsync(colors, m->cols.p, (size_t)m->n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    if (normals && m->has_normals) R3D_HIP(ctx, hipMemcpyAsync(normals, m->nrms.p, (size_t)m->n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return R3D_OK;
+}
+
+// Device-pointer forms for callers that keep their clouds in HBM (the multi-view exchange of config C5: clouds produced by
+// r3d_disparity_to_cloud_resident, gathered by RCCL, registered and transformed without touching the host).  Work is enqueued on
+// the context stream; r3d_icp_dev returns when the loop has finished (it reads the state back), r3d_transform_points_dev is
+// asynchronous.
+int r3d_icp_dev(r3d_ctx *ctx, const r3d_icp_params *p, const double *d_src, int64_t ns, const double *d_src_normals, const double *d_tgt,
+                int64_t nt, const double *d_tgt_normals, const double *init4x4, double *T4x4, r3d_icp_stats *stats) {
+    if (!ctx) return R3D_E_BADARG;
+    if (!p || !d_src || !d_tgt || !T4x4 || ns <= 0 || nt <= 0) return r3d_fail(ctx, R3D_E_BADARG, "icp_dev: bad argument");
+    if (p->mode < 0 || p->mode > 2) return r3d_fail(ctx, R3D_E_BADARG, "icp_dev: mode must be 0 (P2P), 1 (P2PLANE) or 2 (GICP)");
+    if (!(p->max_correspondence_distance > 0)) return r3d_fail(ctx, R3D_E_BADARG, "icp_dev: max_correspondence_distance must be > 0");
+    if (p->mode != MODE_P2P && !d_tgt_normals) return r3d_fail(ctx, R3D_E_BADARG, "icp_dev: target normals required for this mode");
+    if (p->mode == MODE_GICP && !d_src_normals) return r3d_fail(ctx, R3D_E_BADARG, "icp_dev: source normals required for GICP");
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    const auto t_begin = std::chrono::steady_clock::now();
+    DevArena ar(ctx);
+    return icp_core(ctx, ar, p, const_cast<double *>(d_src), ns, const_cast<double *>(d_src_normals), const_cast<double *>(d_tgt), nt,
+                    const_cast<double *>(d_tgt_normals), init4x4, T4x4, stats, t_begin);
+}
+
+int r3d_transform_points_dev(r3d_ctx *ctx, const double *d_xyz, int64_t n, const double *T4x4, int32_t rotate_only, double *d_out) {
+    if (!ctx) return R3D_E_BADARG;
+    if (!d_xyz || !d_out || !T4x4 || n < 0) return r3d_fail(ctx, R3D_E_BADARG, "transform_points_dev: bad argument");
+    if (n == 0) return R3D_OK;
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    k_transform<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(d_xyz, n, to_rigid(T4x4), rotate_only, d_out);
+    R3D_HIP(ctx, hipGetLastError());
+    return R3D_OK;
 }
 
 }  // extern "C"

@@ -4,8 +4,9 @@ fuse()             main.py:34-54 simple_scanning_loop (and test/GICP1.py:134-155
                    initialises the model, every later frame is aligned to the model and appended.
 view_to_cloud()    the join the reference never wrote (Q is loaded at Calib_depth/depth2.py:66 and then unused):
                    StereoSGBM disparity -> reprojectImageTo3D -> voxel_down_sample -> normals.
-multi_view_fuse()  BASELINE config C5: one view per rank, all-gather-v of the per-view clouds, every view registered
-                   to view 0, fused cloud available on every rank (rank 0 hands it to the mesher).
+multi_view_fuse_tensors()  BASELINE config C5: one view per rank, ONE all-gather-v of the per-view clouds (RCCL, clouds stay in
+                   HBM), every view registered to view 0, fused cloud on every rank (rank 0 hands it to the mesher,
+                   mesh_reconstruction.py:22-37); multi_view_fuse() is its host-cloud front end.
 """
 import numpy as np
 
@@ -14,8 +15,54 @@ from .pointcloud import PointCloud, as_arrays
 from .pointcloud_alignment import GeneralizedICPAlignment, PointCloudAlignment
 
 
-def fuse(frames, flavour="icp", verbose=False, **align_kw):
-    """frames: iterable of PointCloud-likes (or None / empty for a failed capture).  Returns the accumulated model."""
+def fuse(frames, flavour="icp", verbose=False, resident=True, ctx=None, log=None, **align_kw):
+    """frames: iterable of PointCloud-likes (or None / empty for a failed capture).  Returns the accumulated model.
+    flavour "icp": main.py:34-54 (align_point_clouds(frame, model, threshold=0.02, voxel_size=0.01, max_iter=100), model += aligned);
+    flavour "gicp": test/GICP1.py:134-155 (registration_generalized_icp of the frame against the whole model, model += aligned,
+    model.estimate_normals(Hybrid(0.05, 30))).  align_kw: threshold / voxel_size / max_iter (icp), threshold (gicp).
+    resident (default): the model stays in HBM across frames (cloud_ops.ResidentModel): per frame only the frame goes up and the
+    4x4 comes back, the model is downloaded once at the end.  resident=False drives the drop-in classes with a host-side model
+    exactly as the reference's loop does (identical results; every frame then re-uploads the whole model).
+    `log` (list) receives the registration result of every aligned frame."""
+    if not resident:
+        return _fuse_host(frames, flavour, verbose, log, **align_kw)
+    model = None
+    for frame in frames:
+        if frame is None or len(as_arrays(frame)[0]) == 0:
+            if verbose:
+                print("No valid point cloud captured, skipping frame.")      # main.py:53-54
+            continue
+        p, c, n = as_arrays(frame)
+        if model is None:
+            model = cloud_ops.ResidentModel(ctx)
+            # main.py:42-45: points + colors only; GICP1.py:139-141: normals as well
+            model.append(p, c if c is not None else None, n if flavour == "gicp" else None)
+            continue
+        if flavour == "icp":
+            if verbose:                                                      # the three progress lines of align_point_clouds
+                print("Downsampling point clouds using voxel size:", align_kw.get("voxel_size", 0.01))
+                print("Estimating normals on CPU...")
+                print("Performing ICP alignment using CUDA...")
+            vs = align_kw.get("voxel_size", 0.01)
+            res = model.align_append(p, align_kw.get("threshold", 0.02), vs, align_kw.get("max_iter", 100), cloud_ops.P2P, 2 * vs, 30,
+                                     source_colors=c)
+        else:
+            if n is None:                                                    # GICP1.py:94-95
+                n = cloud_ops.estimate_normals(p, 0.05, 30, ctx=ctx)
+            if not model.size()[2]:                                          # GICP1.py:96-97
+                model.estimate_normals(0.05, 30)
+            res = model.register_append(p, align_kw.get("threshold", 0.02), cloud_ops.GICP, 30, source_colors=c, source_normals=n)
+            model.estimate_normals(0.05, 30)                                 # GICP1.py:148
+        if log is not None:
+            log.append(res)
+    if model is None:
+        return PointCloud()
+    pts, cols, nrm = model.download()
+    model.close()
+    return PointCloud(pts, cols, nrm)
+
+
+def _fuse_host(frames, flavour, verbose, log, **align_kw):
     model = PointCloud()
     aligner = PointCloudAlignment(verbose=verbose) if flavour == "icp" else GeneralizedICPAlignment()
     for frame in frames:
@@ -31,6 +78,8 @@ def fuse(frames, flavour="icp", verbose=False, **align_kw):
                 model.normals = n.copy()
             continue
         aligned = aligner.align_point_clouds(frame, model, **align_kw)
+        if log is not None:
+            log.append(aligner.last_result)
         model += aligned                                                     # main.py:49
         if flavour == "gicp":                                                # GICP1.py:148: re-estimate on the model
             model.estimate_normals(radius=0.05, max_nn=30)
@@ -82,32 +131,110 @@ def view_to_cloud(left, right, Q, matcher, voxel=0.01, normal_radius=None, max_n
     return PointCloud(pts, normals=nrm)
 
 
-def multi_view_fuse(local_clouds, n_views, threshold=0.02, mode=cloud_ops.GICP, max_iteration=30, register=None):
-    """local_clouds: {view_id: PointCloud with normals} owned by this rank (distributed.shard_views).
-    Exchange once, register every owned view to view 0, exchange the 4x4 transforms, return
-    (fused PointCloud, {view_id: T}).  `register` may replace the HIP registration (the CPU tests inject a stub)."""
-    payload = {}
+def view_to_cloud_tensors(d_left, d_right, d_disp, width, height, Q, matcher, out, voxel=0.01, normal_radius=None, max_nn=30,
+                          pose=None, max_depth=None):
+    """One stereo view whose images are already in HBM -> cloud left in HBM.  d_left / d_right / d_disp: device pointers
+    (uint8 images, int16 disparity scratch); out: float64 torch tensor [2, capacity, 3] on the matcher's device that receives
+    points (plane 0) and normals (plane 1).  Returns the tensor view out[:, :n] ([2, n, 3]).  Nothing crosses PCIe but the
+    point count.  Kernels run on the context stream (distributed.init() makes that torch's current stream)."""
+    ctx = matcher.context
+    matcher.compute_device(d_left, d_right, width, height, width, d_disp)
+    cap = out.shape[1]
+    n = cloud_ops.disparity_to_cloud_resident(d_disp, width, height, Q, out[0].data_ptr(), out[1].data_ptr(), cap,
+                                              matcher.getMinDisparity(), max_depth, pose, voxel, normal_radius or 2 * voxel, max_nn,
+                                              ctx=ctx)
+    return out[:, :n]
+
+
+def multi_view_fuse_tensors(local, n_views, threshold=0.02, mode=cloud_ops.GICP, max_iteration=30, register=None, transform=None,
+                            ctx=None, timings=None):
+    """BASELINE config C5 on clouds that live where the exchange runs (HBM under RCCL).  local: {view_id: float64 tensor
+    [2, n, 3]} (points, normals) of the views this rank owns (distributed.shard_views).  Steps: ONE all-gather-v of the clouds
+    (distributed.gather_views) -> every owned view is registered to view 0 (r3d_icp_dev on the gathered blocks, in place) ->
+    the 4x4s are all-gathered -> every view is transformed into the frame of view 0 (r3d_transform_points_dev) into one fused
+    [2, N, 3] tensor, which every rank ends up holding (rank 0 hands it to the mesher, mesh_reconstruction.py:22-37).
+    Returns (fused tensor, {view_id: T}).  `register(src [2,n,3], tgt [2,m,3]) -> 4x4` and `transform(block, T) -> block`
+    replace the HIP calls in the CPU (gloo) tests; with device tensors and no stubs the HIP library does the work.
+    timings (dict, optional) receives exchange_ms / register_ms / fuse_ms measured with events on the shared stream."""
+    import torch
+    dev = distributed.exchange_device()
+    on_gpu = dev.type == "cuda"
+    if not on_gpu and (register is None or transform is None):
+        raise RuntimeError("multi_view_fuse_tensors: host tensors need injected register / transform stubs; the product path "
+                           "runs on device tensors through libr3d_hip.so (no CPU fallback)")
+    if on_gpu and ctx is None:
+        from . import _lib
+        ctx = _lib.default_context(dev.index or 0)
+
+    def mark():
+        if not on_gpu:
+            import time
+            return time.perf_counter()
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def lap(a, b):
+        if not on_gpu:
+            return 1e3 * (b - a)
+        b.synchronize()
+        return a.elapsed_time(b)
+
+    t0 = mark()
+    everyone = distributed.gather_views(local, n_views)
+    t1 = mark()
+    ref = everyone[0]
+    mine = {}
+    for v in local:
+        if v == 0:
+            T = np.eye(4)
+        elif register is not None:
+            T = np.asarray(register(everyone[v], ref), dtype=np.float64)
+        else:
+            src = everyone[v]
+            T = cloud_ops.registration_device(src[0].data_ptr(), src.shape[1], ref[0].data_ptr(), ref.shape[1], threshold, mode=mode,
+                                              max_iteration=max_iteration, d_source_normals=src[1].data_ptr(),
+                                              d_target_normals=ref[1].data_ptr(), ctx=ctx)["T"]
+        mine[v] = T
+    t2 = mark()
+    Ts = distributed.gather_transforms(mine, n_views)
+    total = sum(everyone[v].shape[1] for v in range(n_views))
+    fused = torch.empty((2, total, 3), dtype=torch.float64, device=dev)
+    o = 0
+    for v in range(n_views):
+        blk, n = everyone[v], everyone[v].shape[1]
+        if transform is not None:
+            fused[:, o:o + n] = transform(blk, Ts[v])
+        elif n:
+            cloud_ops.transform_points_device(blk[0].data_ptr(), n, Ts[v], fused[0, o:o + n].data_ptr(), ctx=ctx)
+            cloud_ops.transform_points_device(blk[1].data_ptr(), n, Ts[v], fused[1, o:o + n].data_ptr(), rotate_only=True, ctx=ctx)
+        o += n
+    t3 = mark()
+    if timings is not None:
+        timings.update(exchange_ms=lap(t0, t1), register_ms=lap(t1, t2), fuse_ms=lap(t2, t3))
+    return fused, Ts
+
+
+def multi_view_fuse(local_clouds, n_views, threshold=0.02, mode=cloud_ops.GICP, max_iteration=30, register=None, ctx=None):
+    """Host-cloud front end of multi_view_fuse_tensors.  local_clouds: {view_id: PointCloud with normals} owned by this rank.
+    The clouds go up once (to the device the exchange runs on), everything else stays there; returns
+    (fused PointCloud, {view_id: T}).  `register(src [n,6], tgt [m,6]) -> 4x4` may replace the HIP registration (the CPU tests
+    inject a stub; rows are xyz | normal)."""
+    import torch
+    dev = distributed.exchange_device()
+    local = {}
     for v, pc in local_clouds.items():
         p, _, n = as_arrays(pc)
-        payload[v] = np.concatenate([p, n if n is not None else np.zeros_like(p)], 1)
-    everyone = distributed.gather_rows_by_view(payload, n_views)
-    ref = everyone[0]
-    if register is None:
-        def register(src, tgt):
-            return cloud_ops.registration(src[:, :3], tgt[:, :3], threshold, mode=mode, max_iteration=max_iteration,
-                                          source_normals=src[:, 3:], target_normals=tgt[:, 3:])["T"]
-    mine = {}
-    for v in local_clouds:
-        T = np.eye(4) if v == 0 else np.asarray(register(everyone[v], ref), dtype=np.float64)
-        mine[v] = T.reshape(1, 16)
-    Ts = distributed.gather_rows_by_view(mine, n_views)
-    fused = PointCloud()
-    out_T = {}
-    for v in range(n_views):
-        T = Ts[v].reshape(4, 4)
-        out_T[v] = T
-        blk = everyone[v]
-        pts = blk[:, :3] @ T[:3, :3].T + T[:3, 3]
-        nrm = blk[:, 3:] @ T[:3, :3].T
-        fused += PointCloud(pts, normals=nrm)
-    return fused, out_T
+        local[v] = torch.from_numpy(np.stack([p, n if n is not None else np.zeros_like(p)], 0)).to(dev)
+    reg = tr = None
+    if register is not None:
+        def reg(src, tgt):
+            return register(torch.cat([src[0], src[1]], 1).cpu().numpy(), torch.cat([tgt[0], tgt[1]], 1).cpu().numpy())
+    if dev.type != "cuda" or register is not None:
+        def tr(blk, T):
+            R = torch.from_numpy(np.ascontiguousarray(T[:3, :3])).to(blk.device)
+            t = torch.from_numpy(np.ascontiguousarray(T[:3, 3])).to(blk.device)
+            return torch.stack([blk[0] @ R.T + t, blk[1] @ R.T], 0)
+    fused, Ts = multi_view_fuse_tensors(local, n_views, threshold, mode, max_iteration, reg, tr, ctx)
+    arr = fused.cpu().numpy()
+    return PointCloud(arr[0], normals=arr[1]), Ts

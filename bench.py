@@ -132,6 +132,102 @@ def bench_frame_loop(r3d, ctx, dL, dR, reps=5):
             "value": round(1e3 / ms, 2), "unit": "frames/s", "ms_per_frame": round(ms, 4), "frames": reps}
 
 
+def bench_c5(r3d, ctx, rank, world, n_views=8, reps=3):
+    """BASELINE config C5: an 8-view 8 MP batch, views dealt round-robin to the ranks (one view per GPU at N = 8; all eight on
+    the one GPU at N = 1, so c5.batch_ms at N = 1 vs N = 8 is the strong-scaling figure north_star asks for).  Per rank and view:
+    SGM -> reprojection -> voxel 0.01 -> normals, device-resident; then ONE all-gather-v of the clouds over RCCL (device
+    tensors, no host staging), every owned view registered to view 0 with GICP, all-gather of the 4x4s, every view transformed
+    into view 0's frame.  View v shows the same synthetic scene (own texture / noise seed) displaced by a known pose, so the
+    registration has a known answer.  Reported: per-stage ms (max over ranks), the batch time, the fused-cloud checksum (equal on
+    all ranks), the pose error, and the hand-off to the mesher's input on rank 0 (mesh_reconstruction.py:22-37 reads a legacy
+    cloud: D2H + binary PLY as io_formats writes it), which is outside batch_ms."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    Dm = r3d.distributed
+    use_dist = dist.is_available() and dist.is_initialized()
+    views = Dm.shard_views(n_views, rank, world)
+    Q = r3d.pipeline.scaled_Q(np.load(os.path.join(ROOT, "tests", "golden", "jetson_stereo_8MP_stereo.npz"))["Q"], W / 960.0, unit=1e-3)
+    poses = {v: (np.eye(4) if v == 0 else r3d.synth.rigid((0.2 * v, 1.0, 0.1 * (v % 3)), 0.25 + 0.05 * v,
+                                                            (0.002 + 0.0005 * v, -0.0015, 0.001 * (v % 4)))) for v in range(n_views)}
+    m = r3d.StereoSGBM_create(numDisparities=D, mode=r3d.STEREO_SGBM_MODE_SGBM_3WAY, **C2_KW)
+    m._ctx = ctx
+    stream = torch.cuda.Stream()
+    cap = 1 << 20
+    out = {}
+    with torch.cuda.stream(stream):
+        ctx.set_stream(stream.cuda_stream)          # library kernels, RCCL and torch ops share one stream: ordered without events
+        try:
+            imgs = {}
+            for v in views:
+                L, R, _ = r3d.synth.stereo_pair(W, H, D, seed=20241008 + v)
+                imgs[v] = (torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda())
+            d_disp = torch.empty(W * H, dtype=torch.int16, device="cuda")
+            bufs = {v: torch.empty((2, cap, 3), dtype=torch.float64, device="cuda") for v in views}
+            best = None
+            for rep in range(reps + 1):             # rep 0 warms arenas, RCCL channels and the matcher workspace
+                if use_dist:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                local = {}
+                for v in views:
+                    local[v] = r3d.pipeline.view_to_cloud_tensors(imgs[v][0].data_ptr(), imgs[v][1].data_ptr(), d_disp.data_ptr(), W, H, Q, m,
+                                                                  bufs[v], voxel=0.01, max_nn=30, max_depth=3.0,
+                                                                  pose=np.linalg.inv(poses[v]))
+                e1.record()
+                tm = {}
+                fused, Ts = r3d.pipeline.multi_view_fuse_tensors(local, n_views, threshold=0.02, mode=r3d.cloud_ops.GICP,
+                                                                  max_iteration=30, ctx=ctx, timings=tm)
+                torch.cuda.synchronize()
+                if use_dist:
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                wall = 1e3 * (time.perf_counter() - t0)
+                tm["view_ms"] = e0.elapsed_time(e1)
+                tm["batch_ms"] = wall
+                if rep and (best is None or wall < best["batch_ms"]):
+                    best = dict(tm)
+            stages = torch.tensor([best[k] for k in ("view_ms", "exchange_ms", "register_ms", "fuse_ms", "batch_ms")], dtype=torch.float64, device="cuda")
+            chk = torch.stack([fused[0].sum(0), fused[1].sum(0)]).reshape(-1)                    # 6 numbers
+            if use_dist:
+                dist.all_reduce(stages, op=dist.ReduceOp.MAX)
+                allc = [torch.empty_like(chk) for _ in range(world)]
+                dist.all_gather(allc, chk)
+                same = all(torch.equal(allc[0], c) for c in allc)
+            else:
+                same = True
+            terr = max(float(np.abs(Ts[v] - poses[v]).max()) for v in range(n_views))
+            st = stages.cpu().numpy()
+            out = {"workload": f"C5: {n_views} views of 3264x2448 D=128, {len(views)} per rank on {world} rank(s): SGM -> cloud (voxel 0.01, "
+                               "normals k30) resident in HBM -> all-gather-v (RCCL, device tensors) -> GICP of every view to view 0 -> "
+                               "all-gather of the 4x4s -> fused cloud on every rank",
+                   "n_views": n_views, "views_per_rank": len(views), "view_ms": round(float(st[0]), 3), "exchange_ms": round(float(st[1]), 3),
+                   "register_ms": round(float(st[2]), 3), "fuse_ms": round(float(st[3]), 3), "batch_ms": round(float(st[4]), 3),
+                   "views_per_s": round(1e3 * n_views / float(st[4]), 2), "fused_points": int(fused.shape[1]),
+                   "fused_checksum": [float(x) for x in chk.cpu().numpy()], "checksum_equal_on_all_ranks": bool(same),
+                   "pose_error_max_abs": terr, "collective": ("rccl all_gather_into_tensor on device tensors" if use_dist else "single rank: no collective issued"),
+                   "stage_times": "max over ranks of the best of %d repetitions; batch_ms is wall time between barriers" % reps}
+            if rank == 0:                            # hand-off to the mesher's input (outside batch_ms)
+                t0 = time.perf_counter()
+                arr = fused.cpu().numpy()
+                pc = r3d.PointCloud(arr[0], normals=arr[1])
+                t1 = time.perf_counter()
+                path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"r3d_c5_fused_{os.getpid()}.ply")
+                r3d.io_formats.write_ply(path, pc.points, normals=pc.normals)
+                t2 = time.perf_counter()
+                out["handoff"] = {"download_ms": round(1e3 * (t1 - t0), 2), "write_ply_ms": round(1e3 * (t2 - t1), 2),
+                                  "ply_bytes": os.path.getsize(path), "consumer": "mesh_reconstruction.py:22-37 (Poisson, CPU; out of scope)"}
+                os.remove(path)
+        finally:
+            torch.cuda.synchronize()
+            ctx.set_stream(None)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +240,8 @@ def main():
                          "(batch entry point) and one depth2.py frame iteration (remap, both matchers, WLS filter, "
                          "normalize).  Off by default so that a rocprofv3 --stats summary of the default command "
                          "averages every SGM kernel over un-overlapped C2 launches only, like the `roofline` object")
+    ap.add_argument("--no-c5", action="store_true", help="skip the C5 leg (8-view batch: view chain -> RCCL all-gather-v -> registration)")
+    ap.add_argument("--repeats", type=int, default=5, help="extra repetitions of the K-step timed region for ms_per_step min / median")
     ap.add_argument("--lanes", type=int, default=1,
                     help="maps in flight per GPU. 1 (default): strictly one map after the other, so that the per-kernel HIP-event "
                          "durations behind `roofline` are uncontended and agree with rocprofv3 --stats; 3: the K maps go through "
@@ -153,15 +251,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    r3d = importlib.import_module("3d_reconstruction_project_amd")
+    ctx = r3d.Context(local_rank)
     dist = None
     if world > 1 or os.environ.get("R3D_FORCE_DIST"):      # R3D_FORCE_DIST: rehearse the multi-rank code path with one rank
         import torch
         import torch.distributed as dist
+        # binds this rank to GPU LOCAL_RANK before any other GPU call and opens the RCCL group; the SGM context keeps its own
+        # stream (the C5 leg switches it to the stream it shares with torch / RCCL)
         torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    r3d = importlib.import_module("3d_reconstruction_project_amd")
-    ctx = r3d.Context(local_rank)
     L, R, _ = r3d.synth.stereo_pair(W, H, D, seed=20241008 + rank)
     dL, dR = ctx.to_device(L), ctx.to_device(R)
     lanes = max(1, min(args.lanes, 3))
@@ -184,9 +284,9 @@ def main():
         m.compute_batch_device([dL] * nw, [dR] * nw, W, H, W, [dDs[i % lanes] for i in range(nw)])
     ctx.set_profiling(True)
     ctx.sgbm_profile()                         # reset accumulators
+    e0, e1 = ctx.event(), ctx.event()          # created before the clock starts
     barrier()
     t0 = time.perf_counter()
-    e0, e1 = ctx.event(), ctx.event()
     ctx.record(e0)
     if lanes == 1:
         for _ in range(args.steps):
@@ -200,6 +300,23 @@ def main():
     elapsed = time.perf_counter() - t0
     dev_ms = ctx.elapsed_ms(e0, e1)
     prof = ctx.sgbm_profile()                  # average per-kernel launch duration over the timed region (HIP events)
+    # robustness: the same K-step region repeated (one map in flight, profiling events off); `value` stays the first region's
+    rep_ms = []
+    ctx.set_profiling(False)
+    for _ in range(max(0, args.repeats)):
+        barrier()
+        tr = time.perf_counter()
+        if lanes == 1:
+            for _ in range(args.steps):
+                m.compute_device(dL, dR, W, H, W, dD)
+        else:
+            m.compute_batch_device([dL] * args.steps, [dR] * args.steps, W, H, W, [dDs[i % lanes] for i in range(args.steps)])
+        barrier()
+        rep_ms.append(1e3 * (time.perf_counter() - tr) / args.steps)
+    if dist is not None and rep_ms:
+        t = torch.tensor(rep_ms, dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rep_ms = [float(x) for x in t.cpu().numpy()]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -219,6 +336,10 @@ def main():
         gicp_multi = dict(gm, value=round(float(tsum[0].item()), 2), ms_per_iteration=round(float(tmax[1].item()), 4),
                           per_gpu=round(float(tsum[0].item()) / world, 2), n_gpus=world,
                           note="sum over ranks of the per-rank rate; ms_per_iteration is the slowest rank's")
+    c5 = None
+    if not args.no_c5:
+        ctx.set_profiling(False)
+        c5 = bench_c5(r3d, ctx, rank, world)
     if rank == 0:
         value = world * args.steps / elapsed
         dom = max(prof, key=prof.get) if prof else None
@@ -226,8 +347,13 @@ def main():
         if dom:
             ach = ALG_BYTES.get(dom, 0) / (prof[dom] * 1e-3) / 1e9
             traffic = None
+            traffic_src = None
             tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
             if os.path.exists(tp):
+                # counters cannot be read from inside the run they describe (rocprofv3 --pmc serialises dispatches): the figure is
+                # the last committed PMC pass, tagged with its file date so a reader can tell whether it belongs to this build
+                traffic_src = "profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE WRITE_SIZE pass, file dated %s)" % time.strftime(
+                    "%Y-%m-%d", time.gmtime(os.path.getmtime(tp)))
                 # HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE doubled: gfx950 tallies 128-B requests at
                 # 64 B, MI355X_MICROARCH.md "HBM"; WRITE_SIZE as is; both in KiB), written by tools/pmc_summary.py
                 with open(tp) as f:
@@ -235,7 +361,7 @@ def main():
                 if t and "FETCH_SIZE" in t and "WRITE_SIZE" in t:
                     traffic = round((2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024 / 1e9, 3)
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK / 1e9,
-                        "unit": "GB/s", "frac": round(ach * 1e9 / HBM_PEAK, 4), "traffic": traffic, "traffic_unit": "GB/launch",
+                        "unit": "GB/s", "frac": round(ach * 1e9 / HBM_PEAK, 4), "traffic": traffic, "traffic_unit": "GB/launch", "traffic_source": traffic_src,
                         "kernel_ms": {k: round(v, 4) for k, v in prof.items()},
                         "note": ("kernel durations are HIP-event brackets on each lane's stream; with %d maps in flight they "
                                  "include the time a kernel shares the chip with other maps' kernels" % lanes) if lanes > 1 else None,
@@ -308,7 +434,9 @@ def main():
                                       "MODE_SGBM_3WAY (depth2.py params), one pair per GPU resident in HBM",
                           "parallelism": f"dp{world} (one view per GPU, no collective in the SGM step)",
                           "maps_in_flight_per_gpu": lanes},
-               "roofline": roofline, "cpu_baseline": cpu, "pipelined": piped, "frame_loop": frame_loop, "secondary": gicp}
+               "ms_per_step_repeats": ({"n": len(rep_ms), "min": round(min(rep_ms), 4), "median": round(sorted(rep_ms)[len(rep_ms) // 2], 4),
+                                        "max": round(max(rep_ms), 4)} if rep_ms else None),
+               "roofline": roofline, "cpu_baseline": cpu, "pipelined": piped, "frame_loop": frame_loop, "secondary": gicp, "c5": c5}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -222,6 +222,49 @@ int r3d_align_point_clouds(r3d_ctx *ctx, const r3d_align_params *p, const double
                            const double *tgt, int64_t nt, const double *init4x4, double *out_xyz, double *out_colors,
                            double *out_normals, int64_t *out_n, double *T4x4, r3d_icp_stats *stats);
 
+/* ---- resident scan-loop model: the growing `combined_pcd` of main.py:28,34-54 and test/GICP1.py:134-155 kept in HBM -----------
+ * The reference passes the whole accumulated cloud to align_point_clouds for every frame (main.py:48), which down-samples it
+ * again (pointcloud_alignment.py:23), and appends the aligned frame (main.py:49).  An r3d_model owns device buffers for the
+ * model's points / colours / normals: per frame only the frame goes up and the 4x4 + statistics come down.  Each call runs the
+ * kernels of the one-shot entry points on the same values in the same order (the model is re-voxelised from its resident
+ * points), so the results equal those of r3d_align_point_clouds / r3d_icp + `+=` on host clouds.  Attributes follow the legacy
+ * operator+=: colours / normals survive an append only if the model is empty or carries them AND the appended cloud does. */
+typedef struct r3d_model r3d_model;
+int r3d_model_create(r3d_ctx *ctx, r3d_model **out);
+void r3d_model_destroy(r3d_model *m);
+int r3d_model_clear(r3d_model *m);
+int r3d_model_size(r3d_model *m, int64_t *n, int32_t *has_colors, int32_t *has_normals);
+/* combined.points = frame.points ... (main.py:42-45) and `combined += cloud` for host clouds; colors / normals may be NULL */
+int r3d_model_append(r3d_model *m, const double *xyz, const double *colors, const double *normals, int64_t n);
+/* main.py:48-49: aligned = align_point_clouds(frame, combined, threshold, voxel_size, max_iter); combined += aligned.
+ * Normals are estimated only where they can reach a result (target normals for the plane / GICP estimators, source normals
+ * for GICP or when the model carries normals): the point-to-point estimator never reads them and += drops them otherwise.
+ * *appended (may be NULL) = points added (the down-sampled frame). */
+int r3d_model_align_append(r3d_model *m, const r3d_align_params *p, const double *src, const double *src_colors, int64_t ns,
+                           double *T4x4, r3d_icp_stats *stats, int64_t *appended);
+/* test/GICP1.py:145-146: aligned = align_point_clouds(frame, combined) (registration of the frame against the WHOLE model with
+ * its normals, :99-103, from identity); combined += aligned.  src_colors / src_normals may be NULL where the mode allows. */
+int r3d_model_register_append(r3d_model *m, const r3d_icp_params *p, const double *src, const double *src_colors, const double *src_normals,
+                              int64_t ns, double *T4x4, r3d_icp_stats *stats);
+/* test/GICP1.py:148: combined.estimate_normals(KDTreeSearchParamHybrid(radius, max_nn)); existing normals keep their orientation */
+int r3d_model_estimate_normals(r3d_model *m, double radius, int32_t max_nn);
+/* host arrays with room for r3d_model_size() triplets; colors / normals may be NULL (and are left alone when the model has none) */
+int r3d_model_download(r3d_model *m, double *xyz, double *colors, double *normals);
+
+/* ---- device-pointer forms (clouds that stay in HBM: the multi-view exchange of BASELINE config C5) -----------------------------
+ * r3d_disparity_to_cloud_resident = r3d_disparity_to_cloud_dev with DEVICE output arrays (capacity triplets each): the cloud is
+ * left in the caller's device buffers, ordered on the context stream (r3d_set_stream lets that be the caller's / torch's
+ * stream, so an RCCL collective enqueued there afterwards sees it); only *out_n comes back to the host.
+ * r3d_icp_dev = r3d_icp on device clouds (returns when the loop has finished).  r3d_transform_points_dev = r3d_transform_points
+ * on device arrays, asynchronous on the context stream; d_out may equal d_xyz. */
+int r3d_disparity_to_cloud_resident(r3d_ctx *ctx, const int16_t *d_disp, int32_t w, int32_t h, const double *Q4x4, int32_t min_valid_x16,
+                                    double max_depth, const double *pose4x4, double voxel, double normal_radius, int32_t max_nn,
+                                    int64_t capacity, double *d_out_xyz, double *d_out_normals, int64_t *out_n);
+int r3d_icp_dev(r3d_ctx *ctx, const r3d_icp_params *p, const double *d_src, int64_t ns, const double *d_src_normals, const double *d_tgt,
+                int64_t nt, const double *d_tgt_normals, const double *init4x4, double *T4x4, r3d_icp_stats *stats);
+int r3d_transform_points_dev(r3d_ctx *ctx, const double *d_xyz, int64_t n, const double *T4x4, int32_t rotate_only, double *d_out);
+
+
 /* ---- per-frame stages either side of the matcher in Calib_depth/depth*.py --------------
  * OpenCV is a dependency of the reference that is absent here, and the reference records no output of these calls:
  * parity of this group is UNPINNED (restated from OpenCV 4.x's published algorithms; see oracle/prepost_oracle.py). */

@@ -33,6 +33,27 @@ def _worker(rank, world, port, n_views, q):
         assert len(blocks) == world
         for r, b in enumerate(blocks):
             assert b.shape == (r * 3, 4) and (b[:, 0] == r + np.arange(r * 3)).all()
+        # --- the exchange step on tensors: ragged views, several per rank, blocks come back as contiguous [n, 3] planes
+        import torch
+        owned0 = D.shard_views(n_views, rank, world)
+        loc = {v: torch.arange(2 * (5 + v) * 3, dtype=torch.float64).reshape(2, 5 + v, 3) + 1000.0 * v for v in owned0}
+        allv = D.gather_views(loc, n_views)
+        assert sorted(allv) == list(range(n_views))
+        for v in range(n_views):
+            want = torch.arange(2 * (5 + v) * 3, dtype=torch.float64).reshape(2, 5 + v, 3) + 1000.0 * v
+            assert torch.equal(allv[v], want) and allv[v][0].is_contiguous() and allv[v][1].is_contiguous()
+        Ts = D.gather_transforms({v: np.eye(4) * (v + 1) for v in owned0}, n_views)
+        assert all(np.array_equal(Ts[v], np.eye(4) * (v + 1)) for v in range(n_views))
+        try:
+            D.gather_views({}, n_views) if owned0 else None           # a rank must bring exactly its own views
+            assert not owned0
+        except ValueError:
+            pass
+        try:                                                           # host tensors without stubs: no CPU fallback
+            r3d.pipeline.multi_view_fuse_tensors(loc, n_views)
+            raise AssertionError("expected the product path to refuse host tensors")
+        except RuntimeError as e:
+            assert "no CPU fallback" in str(e)
         # --- sharded multi-view fusion: view v = the same patch displaced by a known translation t_v
         owned = D.shard_views(n_views, rank, world)
         rng = np.random.default_rng(0)
@@ -76,8 +97,14 @@ def test_exchange_and_sharded_fusion_gloo(world, n_views):
 
 
 def test_world_size_one_needs_no_process_group(r3d):
+    import torch
     blocks = r3d.distributed.all_gather_v(np.ones((3, 2)))
     assert len(blocks) == 1 and blocks[0].shape == (3, 2)
+    if not torch.cuda.is_available():                       # single rank, host tensors: the exchange is the identity
+        loc = {v: torch.full((2, 3 + v, 3), float(v), dtype=torch.float64) for v in range(3)}
+        out = r3d.distributed.gather_views(loc, 3)
+        assert all(torch.equal(out[v], loc[v]) for v in range(3))
+        assert np.array_equal(r3d.distributed.gather_transforms({0: np.eye(4)}, 1)[0], np.eye(4))
     assert r3d.distributed.shard_views(8, 1, 4) == [1, 5]
     assert sorted(sum((r3d.distributed.shard_views(8, r, 3) for r in range(3)), [])) == list(range(8))
 

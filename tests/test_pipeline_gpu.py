@@ -68,6 +68,43 @@ def test_fuse_loop_gicp_flavour_all_eight_c4_frames(r3d):
     assert err.max() < 1e-3 and np.quantile(err, 0.999) < 1e-6
 
 
+def test_resident_model_loop_equals_host_model_loop(r3d):
+    """The HBM-resident model (r3d_model_*) must give exactly what the reference-shaped loop over host clouds gives (which
+    re-uploads and re-voxelises the whole model per frame), for both flavours, colours included."""
+    from PIL import Image
+    frames = []
+    for i in (8, 9, 10, 11):
+        d = co.read_png16(os.path.join(GOLDEN, f"output84/depth_{i:05d}.png"))
+        pts, (v, u) = co.backproject(d, INTR)
+        col = np.asarray(Image.open(os.path.join(GOLDEN, "output84/color_00008.png")))[v, u] / 255.0
+        p, c = co.voxel_down_sample(pts, 0.02, colors=col)
+        frames.append((p, c))
+    feed = [r3d.PointCloud(p, colors=c) for p, c in frames]
+    a = r3d.pipeline.fuse(feed, flavour="icp", voxel_size=0.02, threshold=0.04)
+    b = r3d.pipeline.fuse(feed, flavour="icp", voxel_size=0.02, threshold=0.04, resident=False)
+    np.testing.assert_array_equal(a.points, b.points)
+    np.testing.assert_array_equal(a.colors, b.colors)
+    assert a.has_colors() and not a.has_normals() and len(a) > len(frames[0][0])
+    feed = [r3d.PointCloud(p, colors=c, normals=co.estimate_normals_hybrid(p, 0.05, 30)) for p, c in frames]
+    a = r3d.pipeline.fuse(feed, flavour="gicp")
+    b = r3d.pipeline.fuse(feed, flavour="gicp", resident=False)
+    np.testing.assert_array_equal(a.points, b.points)
+    np.testing.assert_array_equal(a.normals, b.normals)
+    np.testing.assert_array_equal(a.colors, b.colors)
+    # container semantics of the resident model
+    m = r3d.cloud_ops.ResidentModel()
+    assert m.size() == (0, False, False)
+    m.append(frames[0][0], frames[0][1])
+    m.append(frames[1][0])                                   # no colours on the appended cloud: legacy += drops them
+    assert m.size() == (len(frames[0][0]) + len(frames[1][0]), False, False)
+    with pytest.raises(r3d.R3DError):
+        r3d.cloud_ops.ResidentModel().align_append(frames[0][0])          # empty model
+    p, c, n = m.download()
+    np.testing.assert_array_equal(p, np.concatenate([frames[0][0], frames[1][0]]))
+    assert c is None and n is None
+    m.close()
+
+
 def test_view_to_cloud_and_single_rank_multi_view(r3d, synth):
     W, H, D = 640, 480, 64
     Q = r3d.pipeline.scaled_Q(np.load(os.path.join(GOLDEN, "jetson_stereo_8MP_stereo.npz"))["Q"], W / 960.0, unit=1e-3)
