@@ -65,6 +65,31 @@ def exported_symbols():
     return sorted(_SIGS)
 
 
+torch_preloaded = None      # True / False once load() has run: whether torch's HIP runtime was in the process before ours
+
+
+def _preload_torch():
+    """ONE HIP runtime per process.  The PyTorch ROCm wheel bundles its own libamdhip64.so / libhsa-runtime64.so with the
+    system library's SONAME (libamdhip64.so.7) but asks for it by the bare name libamdhip64.so: imported AFTER libr3d_hip.so
+    (which needs libamdhip64.so.7 from /opt/rocm) the loader maps a SECOND runtime, and the second one finds no device
+    ("no ROCm-capable device is detected"); imported BEFORE, our DT_NEEDED entry matches the SONAME already in the process and
+    both share torch's runtime.  So when torch is installed it is imported first (set R3D_NO_TORCH_PRELOAD=1 to keep a
+    torch-free process on the system runtime, e.g. for a rocprofv3 pass; distributed.init() then refuses to run)."""
+    global torch_preloaded
+    import sys
+    if "torch" in sys.modules:
+        torch_preloaded = True
+    elif os.environ.get("R3D_NO_TORCH_PRELOAD") == "1":
+        torch_preloaded = False
+    else:
+        import importlib.util
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
+            torch_preloaded = True
+        else:
+            torch_preloaded = False
+
+
 def load():
     """Loads libr3d_hip.so (no GPU needed to dlopen; any compute call needs one)."""
     global _lib
@@ -73,6 +98,7 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with 3d_reconstruction_project_amd/csrc/build.sh "
                 "(or __graft_entry__.build()). There is no CPU fallback.")
+        _preload_torch()
         lib = ctypes.CDLL(LIB_PATH)
         for name, (argt, rest) in _SIGS.items():
             fn = getattr(lib, name)

@@ -100,6 +100,9 @@ void r3d_destroy(r3d_ctx *ctx) {
                 for (int i = 0; i <= R3D_MAX_PROF; i++) (void)hipEventDestroy(ps.ev[i]);
         if (ws.stream) (void)hipStreamDestroy(ws.stream);
         if (ws.done) (void)hipEventDestroy(ws.done);
+        if (ws.aux) (void)hipStreamDestroy(ws.aux);
+        for (hipEvent_t e : ws.slab_ev)
+            if (e) (void)hipEventDestroy(e);
     }
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->icp_ev) (void)hipEventDestroy(ctx->icp_ev);

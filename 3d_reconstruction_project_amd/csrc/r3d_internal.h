@@ -24,6 +24,7 @@ struct r3d_prof_set {
 };
 
 #define R3D_SGM_LANES 3
+#define R3D_SGM_SLABS 8   // most column slabs of the cost / forward-scan overlap (sgm.hip)
 
 // one SGM pipeline lane: its own grow-only workspace, stream and profiling event ring.  Single-map calls use lane 0 on
 // the context stream; r3d_sgbm_compute_batch_dev spreads maps over the lanes so that kernels with complementary
@@ -32,6 +33,8 @@ struct r3d_sgm_ws {
     r3d_buf rec_l, rec_r, cost, cspec, hsum, ltop, ckpt, raw, mins, lrd, flags, spk_l, spk_c;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
+    hipStream_t aux = nullptr;                       // second stream of the lane: cost slabs ahead of the forward scan
+    hipEvent_t slab_ev[R3D_SGM_SLABS + 1] = {};      // [j]: cost of slab j written; [R3D_SGM_SLABS]: fork point
     r3d_prof_set prof[R3D_PROF_SETS];
     int prof_cur = 0;
     bool ev_created = false;

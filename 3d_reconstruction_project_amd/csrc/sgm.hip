@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(COST_NW * 64) k_cost(const uint2 *__restrict__
 template <int LPC, int SH2, bool TRACK, bool VCH, int NWAVE>
 __global__ void __launch_bounds__(NWAVE * 64) k_cost2(const uint2 *__restrict__ recL, const uint2 *__restrict__ recR, SgmGeom g,
                                                             int *__restrict__ cvol, int *__restrict__ cspec, int BAND, int nMain,
-                                                            int *__restrict__ maxc, int *__restrict__ ltvol) {
+                                                            int *__restrict__ maxc, int *__restrict__ ltvol, int tile0) {
     constexpr int NPL = 8, CW = 64 / LPC, TC = NWAVE * CW, TO = TC - 2 * SH2, DP = 16 * LPC, DPW = NPL * LPC;
     constexpr int R = 2 * SH2 + 1, NRR = TC + DP, NT = NWAVE * 64;
     // pair words: 6 dwords per right pixel, plus 8 dwords of padding after every 16 pixels: lanes of one column group
@@ -479,7 +479,7 @@ __global__ void __launch_bounds__(NWAVE * 64) k_cost2(const uint2 *__restrict__ 
     __shared__ int sV[2][TC * DPW];       // vertical box sums of the tile, double buffered
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, k = lane % LPC, grp = lane / LPC;
     const int cl = w * CW + grp;                       // local column 0..TC-1
-    const int t0 = blockIdx.x * TO;                    // first OUTPUT cost column of the tile
+    const int t0 = (blockIdx.x + tile0) * TO;          // first OUTPUT cost column of the tile (tile0: column-slab launches)
     const int xc = min(max(t0 - SH2 + cl, 0), g.W1 - 1);   // cost column this lane evaluates (replicated at the borders)
     const int x = xc + g.minX1;                        // image column
     const int r_base = max(t0 - SH2, 0) + g.minX1 - g.minD - (DP - 1);
@@ -826,8 +826,13 @@ __global__ void __launch_bounds__(64) k_vscan(const int *__restrict__ cvol, cons
 //            runs over the same registers and streams L_left + L_right to HBM.
 // HBM traffic per row: C read twice, sum written once, + 2 * 8 B * 64 * W1/K of checkpoints (6 % at K = 32).
 // A tail of W1 % K columns uses the v1 scheme (L_left parked in the output row).
-template <int NPL, int LPC, int K, bool PADDED>
-__global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int *__restrict__ hvol, int *__restrict__ ckpt, SgmGeom g) {
+// PHASE 3: both phases in one launch (as described above).  PHASE 1 / 2: the two phases as separate launches, phase 1 over the
+// segments [seg0, seg1) only, so that it can follow the cost kernel slab by slab (cost of slab j+1 overlaps the forward chain
+// over slab j): the state entering segment seg0 is read from the checkpoint the previous launch left, the state entering seg1
+// is left for the next one; the launch with seg1 == nfull also runs the tail columns.  Phase 2 only needs the checkpoints.
+template <int NPL, int LPC, int K, bool PADDED, int PHASE = 3>
+__global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int *__restrict__ hvol, int *__restrict__ ckpt, SgmGeom g,
+                                               int seg0, int seg1) {
     constexpr int DPW = NPL * LPC, RPW = 64 / LPC, CKW = (NPL + 1) * 64;   // words per column, rows per wave
     const int lane = threadIdx.x, k = lane % LPC;
     const int yraw = blockIdx.x * RPW + lane / LPC;
@@ -844,8 +849,10 @@ __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int
     int c0[K][NPL], c1[K][NPL], c2[K][NPL], c3[K][NPL], llA[K][NPL], llB[K][NPL];
 #pragma unroll
     for (int j = 0; j < NPL; j++) P[j] = valid ? 0 : PADPK;
+    // phase-1 range launches never read past their own slab (the cost kernel may still be writing the next one)
+    const int seg_hi = PHASE == 1 ? min(seg1, nfull) : nfull;
     auto load_seg = [&](int (&buf)[K][NPL], int sidx) {
-        const int sc = min(max(sidx, 0), max(nfull - 1, 0));
+        const int sc = min(max(sidx, 0), max(seg_hi - 1, 0));
         const int *p = crow + (size_t)sc * K * DPW;
 #pragma unroll
         for (int u = 0; u < K; u++)
@@ -875,18 +882,23 @@ __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int
 #pragma unroll
         for (int u = 0; u < K; u++) sgm_step_g<NPL, LPC, PADDED>(P, minp, cur[u], P1pk, g.P2, first, last, valid);
     };
-    if (nfull > 0) {
-        load_seg(c0, 0); load_seg(c1, 1); load_seg(c2, 2);
+    const int sb = PHASE == 1 ? max(seg0, 0) : 0;
+    if (PHASE & 1) {
+    if (PHASE == 1 && sb > 0) load_ck(sb);
+    if (seg_hi > sb) {
+        load_seg(c0, sb); load_seg(c1, sb + 1); load_seg(c2, sb + 2);
 #pragma unroll 1
-        for (int s0 = 0; s0 < nfull; s0 += 4) {
+        for (int s0 = sb; s0 < seg_hi; s0 += 4) {
             fwd_round(c0, c3, s0);
-            if (s0 + 1 < nfull) fwd_round(c1, c0, s0 + 1);
-            if (s0 + 2 < nfull) fwd_round(c2, c1, s0 + 2);
-            if (s0 + 3 < nfull) fwd_round(c3, c2, s0 + 3);
+            if (s0 + 1 < seg_hi) fwd_round(c1, c0, s0 + 1);
+            if (s0 + 2 < seg_hi) fwd_round(c2, c1, s0 + 2);
+            if (s0 + 3 < seg_hi) fwd_round(c3, c2, s0 + 3);
         }
     }
+    if (PHASE == 1 && seg_hi < nfull) save_ck(seg_hi);     // state entering the next launch's first segment
     // tail columns [nfull*K, W1): forward values parked in the output row (rows beyond the image park nothing: they
     // recompute nothing useful either, their results are never stored)
+    if (PHASE == 3 || seg_hi == nfull)
     for (int x = nfull * K; x < W1; x++) {
         int c[NPL];
 #pragma unroll
@@ -897,6 +909,8 @@ __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int
             for (int j = 0; j < NPL; j++) hrow[(size_t)x * DPW + j] = P[j];
         }
     }
+    }
+    if (!(PHASE & 2)) return;
     // ---- phase 2: backward chain of segment s in lockstep with the recomputed forward chain of segment s-1
     int R[NPL], minr = 0;
 #pragma unroll
@@ -1626,17 +1640,27 @@ int derive_geom(r3d_ctx *ctx, const r3d_sgbm_params *p, int w, int h, SgmGeom &g
     return R3D_OK;
 }
 
+// col_lo / col_hi: cost columns of a column slab (whole tiles: [ceil(col_lo / TO), ceil(col_hi / TO)) of the tile grid, so
+// consecutive slabs partition the tiles); col_hi < 0 = the whole width
 template <int LPC, int SH2, bool TRACK, bool VCH, int NWAVE>
-int launch_cost2_n(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st) {
+int launch_cost2_n(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st, int col_lo, int col_hi) {
     constexpr int CW = 64 / LPC, TC = NWAVE * CW, TO = TC - 2 * SH2;
     if (TO <= 0) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "sgbm: tile too small for this block size");
-    const int tiles = (g.W1 + TO - 1) / TO;
+    const int all_tiles = (g.W1 + TO - 1) / TO;
+    const int tile_lo = col_hi < 0 ? 0 : std::min((col_lo + TO - 1) / TO, all_tiles);
+    const int tile_hi = col_hi < 0 ? all_tiles : std::min((col_hi + TO - 1) / TO, all_tiles);
+    const int tiles = tile_hi - tile_lo;
+    if (tiles <= 0) return R3D_OK;
     // size the row bands so that one round of workgroups fills the chip (each band pays 2*SH2 extra rows of pixel cost)
-    int per_cu = 1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_cost2<LPC, SH2, TRACK, VCH, NWAVE>, NWAVE * 64, 0);
-    if (per_cu < 1) per_cu = 1;
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    static int per_cu = 0, cus = 0;   // queried once per instantiation (slab launches call this several times per map)
+    if (per_cu == 0) {
+        int v = 1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, (const void *)k_cost2<LPC, SH2, TRACK, VCH, NWAVE>, NWAVE * 64, 0);
+        per_cu = v < 1 ? 1 : v;
+        int c = 256;
+        (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        cus = c < 1 ? 256 : c;
+    }
     const int slots = per_cu * cus;
     int nb = slots / tiles;
     if (nb < 1) nb = 1;
@@ -1647,7 +1671,7 @@ int launch_cost2_n(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t s
     int *maxc = (int *)ws.flags.p + 8;
     if (TRACK) R3D_HIP(ctx, hipMemsetAsync(maxc, 0, 4, st));
     k_cost2<LPC, SH2, TRACK, VCH, NWAVE><<<dim3(tiles, VCH ? 4 : nMain + nSpec), NWAVE * 64, 0, st>>>(
-        (const uint2 *)ws.rec_l.p, (const uint2 *)ws.rec_r.p, g, (int *)ws.cost.p, (int *)ws.cspec.p, BAND, nMain, maxc, (int *)ws.ltop.p);
+        (const uint2 *)ws.rec_l.p, (const uint2 *)ws.rec_r.p, g, (int *)ws.cost.p, (int *)ws.cspec.p, BAND, nMain, maxc, (int *)ws.ltop.p, tile_lo);
     R3D_HIP(ctx, hipGetLastError());
     if (TRACK) {
         // data-dependent half of the exact-int16 envelope: only reached when the static bound cannot prove it
@@ -1660,33 +1684,33 @@ int launch_cost2_n(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t s
     return R3D_OK;
 }
 template <int LPC, int SH2, bool TRACK, bool VCH>
-int launch_cost2_t(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st) {
+int launch_cost2_t(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st, int col_lo, int col_hi) {
     // 8 waves = 64-column tiles (2*SH2 halo columns); R3D_COST_NWAVE=4 selects 32-column tiles for A/B measurements
     static const bool four = [] { const char *e = getenv("R3D_COST_NWAVE"); return e && !strcmp(e, "4"); }();
     if constexpr (LPC == 8 && 4 * (64 / LPC) > 2 * SH2) {
-        if (four) return launch_cost2_n<LPC, SH2, TRACK, VCH, 4>(ctx, ws, g, st);
+        if (four) return launch_cost2_n<LPC, SH2, TRACK, VCH, 4>(ctx, ws, g, st, col_lo, col_hi);
     }
-    return launch_cost2_n<LPC, SH2, TRACK, VCH, 8>(ctx, ws, g, st);
+    return launch_cost2_n<LPC, SH2, TRACK, VCH, 8>(ctx, ws, g, st, col_lo, col_hi);
 }
 template <int LPC, bool VCH>
-int launch_cost2_l(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st) {
+int launch_cost2_l(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st, int col_lo, int col_hi) {
     const bool track = (long)(2 * g.SH2 + 1) * (2 * g.SH2 + 1) * (2L * g.ftzero + 63) > 16383;
     switch (g.SH2) {
-        case 0: return launch_cost2_t<LPC, 0, false, VCH>(ctx, ws, g, st);
-        case 1: return launch_cost2_t<LPC, 1, false, VCH>(ctx, ws, g, st);
-        case 2: return launch_cost2_t<LPC, 2, false, VCH>(ctx, ws, g, st);
-        case 3: return track ? launch_cost2_t<LPC, 3, true, VCH>(ctx, ws, g, st) : launch_cost2_t<LPC, 3, false, VCH>(ctx, ws, g, st);
-        case 4: return track ? launch_cost2_t<LPC, 4, true, VCH>(ctx, ws, g, st) : launch_cost2_t<LPC, 4, false, VCH>(ctx, ws, g, st);
-        default: return launch_cost2_t<LPC, 5, true, VCH>(ctx, ws, g, st);
+        case 0: return launch_cost2_t<LPC, 0, false, VCH>(ctx, ws, g, st, col_lo, col_hi);
+        case 1: return launch_cost2_t<LPC, 1, false, VCH>(ctx, ws, g, st, col_lo, col_hi);
+        case 2: return launch_cost2_t<LPC, 2, false, VCH>(ctx, ws, g, st, col_lo, col_hi);
+        case 3: return track ? launch_cost2_t<LPC, 3, true, VCH>(ctx, ws, g, st, col_lo, col_hi) : launch_cost2_t<LPC, 3, false, VCH>(ctx, ws, g, st, col_lo, col_hi);
+        case 4: return track ? launch_cost2_t<LPC, 4, true, VCH>(ctx, ws, g, st, col_lo, col_hi) : launch_cost2_t<LPC, 4, false, VCH>(ctx, ws, g, st, col_lo, col_hi);
+        default: return launch_cost2_t<LPC, 5, true, VCH>(ctx, ws, g, st, col_lo, col_hi);
     }
 }
-int launch_cost2(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st, bool vch) {
-    if (vch) return g.NP == 1 ? launch_cost2_l<8, true>(ctx, ws, g, st) : launch_cost2_l<16, true>(ctx, ws, g, st);
+int launch_cost2(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st, bool vch, int col_lo = 0, int col_hi = -1) {
+    if (vch) return g.NP == 1 ? launch_cost2_l<8, true>(ctx, ws, g, st, 0, -1) : launch_cost2_l<16, true>(ctx, ws, g, st, 0, -1);
     switch (g.DP) {  // LPC = DP / 16 lanes per column
-        case 32: return launch_cost2_l<2, false>(ctx, ws, g, st);
-        case 64: return launch_cost2_l<4, false>(ctx, ws, g, st);
-        case 128: return launch_cost2_l<8, false>(ctx, ws, g, st);
-        default: return launch_cost2_l<16, false>(ctx, ws, g, st);
+        case 32: return launch_cost2_l<2, false>(ctx, ws, g, st, col_lo, col_hi);
+        case 64: return launch_cost2_l<4, false>(ctx, ws, g, st, col_lo, col_hi);
+        case 128: return launch_cost2_l<8, false>(ctx, ws, g, st, col_lo, col_hi);
+        default: return launch_cost2_l<16, false>(ctx, ws, g, st, col_lo, col_hi);
     }
 }
 
@@ -1865,7 +1889,53 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
             k_cost<2><<<grid, COST_NW * 64, lds, st>>>((const uint2 *)ws.rec_l.p, (const uint2 *)ws.rec_r.p, g, (int *)ws.cost.p, (int *)ws.cspec.p, TX, BAND, nMain, RING);
         }
         R3D_HIP(ctx, hipGetLastError());
+    }
+    // Column-slab overlap of the cost kernel with the forward phase of the horizontal scan (R3D_SGM_OVERLAP = number of slabs,
+    // default 4; 0 or 1: one kernel after the other).  The forward chain at column x only needs C of columns <= x, so the
+    // cost kernel runs slab by slab (left to right) on a second stream while k_hscan2<PHASE 1> follows one slab behind on the
+    // map's own stream; the backward phase (PHASE 2), which needs every checkpoint, and everything after it stay as they were.
+    // A kernel of this kind lasts as long as ONE of its waves' chains, whatever the number of waves, so splitting by ROWS
+    // (or running the vertical scan behind the backward sweep) shortens nothing; only the cost kernel, whose work is not a
+    // chain, can hide behind a chain kernel.
+    static const int n_slabs = [] { const char *e = getenv("R3D_SGM_OVERLAP"); const int v = e ? atoi(e) : 4; return v < 2 ? 0 : (v > R3D_SGM_SLABS ? R3D_SGM_SLABS : v); }();
+    static const bool rows2_env = [] { const char *e = getenv("R3D_HSCAN_ROWS"); return e && !strcmp(e, "2"); }();
+    constexpr int KOV = 16;
+    const bool track = (long)(2 * g.SH2 + 1) * (2 * g.SH2 + 1) * (2L * g.ftzero + 63) > 16383;
+    const bool overlapped = !use_v1 && n_slabs >= 2 && g.DP == 128 && !rows2_env && !track && g.W1 / KOV >= 8 * n_slabs;
+    if (overlapped) {
+        if (!ws.aux) R3D_HIP(ctx, hipStreamCreateWithFlags(&ws.aux, hipStreamNonBlocking));
+        if (!ws.slab_ev[0])
+            for (int j = 0; j <= R3D_SGM_SLABS; j++) R3D_HIP(ctx, hipEventCreateWithFlags(&ws.slab_ev[j], hipEventDisableTiming));
+        const int nfull = g.W1 / KOV, nwaves = (h + 3) / 4;
+        const bool padded = g.D != g.DP;
+        if ((rc = r3d_reserve(ctx, ws.ckpt, (size_t)nwaves * (nfull + 1) * (4 + 1) * 64 * 4))) return rc;
+        const int *cp = (const int *)ws.cost.p;
+        int *hp = (int *)ws.hsum.p, *kp = (int *)ws.ckpt.p;
+        r3d_prof_mark(ctx, ws, st, "cost+hscan_fwd");
+        R3D_HIP(ctx, hipEventRecord(ws.slab_ev[R3D_SGM_SLABS], st));            // fork: prefilter done (and the previous map's readers of C)
+        R3D_HIP(ctx, hipStreamWaitEvent(ws.aux, ws.slab_ev[R3D_SGM_SLABS], 0));
+        int seg_lo = 0;
+        for (int j = 0; j < n_slabs; j++) {
+            const int seg_hi = j == n_slabs - 1 ? nfull : (int)((long)nfull * (j + 1) / n_slabs);
+            const int col_lo = seg_lo * KOV, col_hi = j == n_slabs - 1 ? g.W1 : seg_hi * KOV;
+            if ((rc = launch_cost2(ctx, ws, g, ws.aux, false, col_lo, col_hi))) return rc;
+            R3D_HIP(ctx, hipEventRecord(ws.slab_ev[j], ws.aux));
+            seg_lo = seg_hi;
+        }
+        seg_lo = 0;
+        for (int j = 0; j < n_slabs; j++) {
+            const int seg_hi = j == n_slabs - 1 ? nfull : (int)((long)nfull * (j + 1) / n_slabs);
+            R3D_HIP(ctx, hipStreamWaitEvent(st, ws.slab_ev[j], 0));
+            if (padded) k_hscan2<4, 16, KOV, true, 1><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, seg_lo, seg_hi);
+            else k_hscan2<4, 16, KOV, false, 1><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, seg_lo, seg_hi);
+            seg_lo = seg_hi;
+        }
+        R3D_HIP(ctx, hipGetLastError());
+        r3d_prof_mark(ctx, ws, st, "hscan_bwd");
+        if (padded) k_hscan2<4, 16, KOV, true, 2><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, nfull);
+        else k_hscan2<4, 16, KOV, false, 2><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, nfull);
     } else {
+    if (!use_v1) {
         r3d_prof_mark(ctx, ws, st, "cost");
         if ((rc = launch_cost2(ctx, ws, g, st, false))) return rc;
     }
@@ -1892,22 +1962,23 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
         const int *cp = (const int *)ws.cost.p;
         int *hp = (int *)ws.hsum.p, *kp = (int *)ws.ckpt.p;
         if (g.DP == 32) {
-            if (padded) k_hscan2<1, 16, K32, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
-            else k_hscan2<1, 16, K32, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
+            if (padded) k_hscan2<1, 16, K32, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, 0);
+            else k_hscan2<1, 16, K32, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, 0);
         } else if (g.DP == 64) {
-            if (padded) k_hscan2<2, 16, K64, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
-            else k_hscan2<2, 16, K64, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
+            if (padded) k_hscan2<2, 16, K64, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, 0);
+            else k_hscan2<2, 16, K64, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, 0);
         } else if (four) {
-            if (padded) k_hscan2<4, 16, K1b, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
-            else k_hscan2<4, 16, K1b, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
+            if (padded) k_hscan2<4, 16, K1b, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, 0);
+            else k_hscan2<4, 16, K1b, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, 0);
         } else if (g.NP == 1) {
-            if (padded) k_hscan2<2, 32, K1, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
-            else k_hscan2<2, 32, K1, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
+            if (padded) k_hscan2<2, 32, K1, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, 0);
+            else k_hscan2<2, 32, K1, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, 0);
         } else {
-            if (padded) k_hscan2<4, 32, K2, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
-            else k_hscan2<4, 32, K2, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g);
+            if (padded) k_hscan2<4, 32, K2, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, 0);
+            else k_hscan2<4, 32, K2, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, 0);
         }
     }
+    }  // !overlapped
     R3D_HIP(ctx, hipGetLastError());
 
     r3d_prof_mark(ctx, ws, st, "vscan_wta");

@@ -41,8 +41,11 @@ def init(backend=None, ctx=None):
     a library Context on the same device whose stream is torch's current stream (so library kernels, RCCL collectives and
     torch ops are ordered without events), and the process group ("nccl" when a GPU is visible, else "gloo") if
     WORLD_SIZE > 1 (or R3D_FORCE_DIST is set, to rehearse the collective path with one rank).  Idempotent."""
-    import torch
     from . import _lib
+    if _lib.torch_preloaded is False:
+        raise RuntimeError("libr3d_hip.so was loaded into a torch-free process (R3D_NO_TORCH_PRELOAD=1): importing torch now would "
+                           "bring a second HIP runtime that sees no device; start the process without that variable")
+    import torch
     rank, local_rank, world = dist_env()
     have_gpu = torch.cuda.is_available()
     if backend is None:

@@ -26,18 +26,21 @@ def fuse(frames, flavour="icp", verbose=False, resident=True, ctx=None, log=None
     `log` (list) receives the registration result of every aligned frame."""
     if not resident:
         return _fuse_host(frames, flavour, verbose, log, **align_kw)
-    model = None
+    model = first = None
     for frame in frames:
         if frame is None or len(as_arrays(frame)[0]) == 0:
             if verbose:
                 print("No valid point cloud captured, skipping frame.")      # main.py:53-54
             continue
         p, c, n = as_arrays(frame)
+        if first is None:
+            # main.py:42-45: points + colors only; GICP1.py:139-141: normals as well.  Stays on the host until a second
+            # frame needs a model to register against (a one-frame scan never touches the GPU)
+            first = (p.copy(), None if c is None else c.copy(), n.copy() if (flavour == "gicp" and n is not None) else None)
+            continue
         if model is None:
             model = cloud_ops.ResidentModel(ctx)
-            # main.py:42-45: points + colors only; GICP1.py:139-141: normals as well
-            model.append(p, c if c is not None else None, n if flavour == "gicp" else None)
-            continue
+            model.append(*first)
         if flavour == "icp":
             if verbose:                                                      # the three progress lines of align_point_clouds
                 print("Downsampling point clouds using voxel size:", align_kw.get("voxel_size", 0.01))
@@ -56,7 +59,7 @@ def fuse(frames, flavour="icp", verbose=False, resident=True, ctx=None, log=None
         if log is not None:
             log.append(res)
     if model is None:
-        return PointCloud()
+        return PointCloud(*((first[0], first[1], first[2]) if first is not None else ()))
     pts, cols, nrm = model.download()
     model.close()
     return PointCloud(pts, cols, nrm)

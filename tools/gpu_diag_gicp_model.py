@@ -39,4 +39,20 @@ out["registration"] = rows
 out["target_nx_lt_m099"] = int((mn[:, 0] < -0.99).sum())
 out["source_nx_lt_m099"] = int((fr[2][1][:, 0] < -0.99).sum())
 out["target_unit_norm_err"] = float(np.abs(np.linalg.norm(mn, axis=1) - 1).max())
+# (3) the product's own model after frames 8, 9 and the registration of frame 10 against IT
+feed = [r3d.PointCloud(p, normals=n) for p, n in fr[:2]]
+pm = r3d.pipeline.fuse(feed, flavour="gicp")
+out["product_model_dp"] = float(np.abs(pm.points - mp).max())
+out["product_model_dn"] = float(np.abs(pm.normals - mn).max())
+rows = []
+for it in (18, 19, 20, 21, 22, 25, 30):
+    w = co.registration(fr[2][0], mp, 0.02, mode="gicp", max_iteration=it, relative_fitness=-1, relative_rmse=-1, target_normals=mn,
+                        target_cov=co.covariances_from_normals(mn), source_cov=co.covariances_from_normals(fr[2][1]))
+    g = r3d.cloud_ops.registration(fr[2][0], pm.points, 0.02, mode=2, max_iteration=it, relative_fitness=-1, relative_rmse=-1,
+                                   source_normals=fr[2][1], target_normals=pm.normals)
+    rows.append({"it": it, "corr": [w["correspondences"], g["correspondences"]], "rmse_oracle": w["inlier_rmse"],
+                 "drmse": g["inlier_rmse"] - w["inlier_rmse"], "dT": float(np.abs(g["T"] - w["T"]).max())})
+out["frame10_vs_product_model"] = rows
+g = r3d.cloud_ops.registration(fr[2][0], pm.points, 0.02, mode=2, max_iteration=30, source_normals=fr[2][1], target_normals=pm.normals)
+out["frame10_product_model_iterations"] = g["iterations"]
 print(json.dumps(out))
