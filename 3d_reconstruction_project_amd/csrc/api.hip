@@ -1,10 +1,41 @@
-// api.hip -- context, memory/timing helpers and the extern "C" entry points declared in include/r3d.h.
+// api.hip -- context, memory/timing helpers and the  extern "C" entry points declared in include/r3d.h.
+#include <dlfcn.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "r3d_internal.h"
 
 static std::string g_init_err;
+
+// ---- roctx markers, resolved lazily with dlopen (no link-time dependency on a profiler library) -------------------------------
+namespace {
+typedef int (*roctx_push_fn)(const char *);
+typedef int (*roctx_pop_fn)();
+roctx_push_fn g_roctx_push = nullptr;
+roctx_pop_fn g_roctx_pop = nullptr;
+int g_roctx_state = 0;   // 0: not looked up, 1: available, -1: unavailable / disabled
+void roctx_lookup() {
+    g_roctx_state = -1;
+    const char *e = getenv("R3D_ROCTX");
+    if (e && !strcmp(e, "0")) return;
+    for (const char *lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+        void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        g_roctx_push = (roctx_push_fn)dlsym(h, "roctxRangePushA");
+        g_roctx_pop = (roctx_pop_fn)dlsym(h, "roctxRangePop");
+        if (g_roctx_push && g_roctx_pop) { g_roctx_state = 1; return; }
+    }
+}
+}  // namespace
+void r3d_roctx_push(const char *name) {
+    if (g_roctx_state == 0) roctx_lookup();
+    if (g_roctx_state == 1) (void)g_roctx_push(name);
+}
+void r3d_roctx_pop() {
+    if (g_roctx_state == 1) (void)g_roctx_pop();
+}
+
 
 int r3d_fail(r3d_ctx *ctx, int code, const char *fmt, ...) {
     char buf[512];
@@ -120,6 +151,7 @@ void r3d_destroy(r3d_ctx *ctx) {
 const char *r3d_last_error(const r3d_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_err.c_str(); }
 
 int r3d_sync(r3d_ctx *ctx) {
+    R3D_ROCTX_RANGE("r3d_sync");
     if (!ctx) return R3D_E_BADARG;
     R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return R3D_OK;
@@ -133,16 +165,19 @@ int r3d_set_stream(r3d_ctx *ctx, void *s) {
 void *r3d_get_stream(r3d_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 int r3d_debug_streambench(r3d_ctx *ctx, int32_t mode, int32_t rows, uint64_t row_bytes, int32_t write, int32_t delay, int32_t reps, float *ms) {
+    R3D_ROCTX_RANGE("r3d_debug_streambench");
     if (!ctx || !ms || rows <= 0 || reps <= 0) return R3D_E_BADARG;
     return r3d_streambench_run(ctx, mode, rows, row_bytes, write, delay, reps, ms);
 }
 
 int r3d_selftest(r3d_ctx *ctx) {
+    R3D_ROCTX_RANGE("r3d_selftest");
     if (!ctx) return R3D_E_BADARG;
     return r3d_selftest_run(ctx);
 }
 
 int r3d_dev_alloc(r3d_ctx *ctx, uint64_t bytes, void **out) {
+    R3D_ROCTX_RANGE("r3d_dev_alloc");
     if (!ctx || !out) return R3D_E_BADARG;
     R3D_HIP(ctx, hipSetDevice(ctx->device));
     hipError_t e = hipMalloc(out, bytes ? bytes : 1);
@@ -150,18 +185,21 @@ int r3d_dev_alloc(r3d_ctx *ctx, uint64_t bytes, void **out) {
     return R3D_OK;
 }
 int r3d_dev_free(r3d_ctx *ctx, void *p) {
+    R3D_ROCTX_RANGE("r3d_dev_free");
     if (!ctx) return R3D_E_BADARG;
     R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     R3D_HIP(ctx, hipFree(p));
     return R3D_OK;
 }
 int r3d_copy_h2d(r3d_ctx *ctx, void *d, const void *h, uint64_t bytes) {
+    R3D_ROCTX_RANGE("r3d_copy_h2d");
     if (!ctx || (!d && bytes) || (!h && bytes)) return R3D_E_BADARG;
     R3D_HIP(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
     R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return R3D_OK;
 }
 int r3d_copy_d2h(r3d_ctx *ctx, void *h, const void *d, uint64_t bytes) {
+    R3D_ROCTX_RANGE("r3d_copy_d2h");
     if (!ctx || (!d && bytes) || (!h && bytes)) return R3D_E_BADARG;
     R3D_HIP(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
     R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -217,12 +255,14 @@ int r3d_sgbm_profile(r3d_ctx *ctx, float *ms, int32_t max_slots, char *names, in
 
 int r3d_sgbm_compute_dev(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *d_left, const uint8_t *d_right, int32_t w,
                          int32_t h, int32_t stride, int16_t *d_disp) {
+    R3D_ROCTX_RANGE("r3d_sgbm_compute_dev");
     if (!ctx) return R3D_E_BADARG;
     return r3d_sgm_run(ctx, 0, ctx->stream, p, d_left, d_right, w, h, stride, d_disp);
 }
 
 int r3d_sgbm_compute_batch_dev(r3d_ctx *ctx, const r3d_sgbm_params *p, int32_t n, const uint8_t *const *d_left,
                                const uint8_t *const *d_right, int32_t w, int32_t h, int32_t stride, int16_t *const *d_disp) {
+    R3D_ROCTX_RANGE("r3d_sgbm_compute_batch_dev");
     if (!ctx) return R3D_E_BADARG;
     if (n < 0 || (n > 0 && (!d_left || !d_right || !d_disp))) return r3d_fail(ctx, R3D_E_BADARG, "sgbm batch: bad argument");
     if (n == 0) return R3D_OK;
@@ -252,6 +292,7 @@ int r3d_sgbm_compute_batch_dev(r3d_ctx *ctx, const r3d_sgbm_params *p, int32_t n
 
 int r3d_sgbm_compute(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *left, const uint8_t *right, int32_t w, int32_t h,
                      int32_t stride, int16_t *disp) {
+    R3D_ROCTX_RANGE("r3d_sgbm_compute");
     if (!ctx) return R3D_E_BADARG;
     if (!left || !right || !disp) return r3d_fail(ctx, R3D_E_BADARG, "sgbm: null host pointer");
     if (w <= 0 || h <= 0 || stride < w) return r3d_fail(ctx, R3D_E_BADARG, "sgbm: bad size %dx%d stride %d", w, h, stride);
@@ -268,6 +309,7 @@ int r3d_sgbm_compute(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *left
 }
 
 int r3d_filter_speckles(r3d_ctx *ctx, int16_t *img, int32_t w, int32_t h, int32_t new_val, int32_t max_speckle_size, int32_t max_diff) {
+    R3D_ROCTX_RANGE("r3d_filter_speckles");
     if (!ctx) return R3D_E_BADARG;
     if (!img || w <= 0 || h <= 0) return r3d_fail(ctx, R3D_E_BADARG, "filter_speckles: bad argument");
     R3D_HIP(ctx, hipSetDevice(ctx->device));
@@ -282,6 +324,7 @@ int r3d_filter_speckles(r3d_ctx *ctx, int16_t *img, int32_t w, int32_t h, int32_
 }
 
 int r3d_sgbm_debug_fetch(r3d_ctx *ctx, int16_t *cost, int16_t *hsum, int16_t *raw) {
+    R3D_ROCTX_RANGE("r3d_sgbm_debug_fetch");
     if (!ctx) return R3D_E_BADARG;
     if (ctx->last_w == 0) return r3d_fail(ctx, R3D_E_BADARG, "debug_fetch: no sgbm call yet");
     if (ctx->last_w1 <= 0) return r3d_fail(ctx, R3D_E_BADARG, "debug_fetch: the last call had an empty matching range (all-invalid map), no volumes exist");

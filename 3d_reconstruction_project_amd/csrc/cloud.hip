@@ -1807,11 +1807,13 @@ static int voxel_downsample_impl(r3d_ctx *ctx, const double *xyz, const double *
 
 int r3d_voxel_downsample(r3d_ctx *ctx, const double *xyz, const double *colors, const double *normals, int64_t n, double voxel,
                          double *out_xyz, double *out_colors, double *out_normals, int64_t *out_n) {
+    R3D_ROCTX_RANGE("r3d_voxel_downsample");
     return voxel_downsample_impl(ctx, xyz, colors, normals, n, voxel, out_xyz, out_colors, out_normals, out_n, false);
 }
 
 int r3d_voxel_downsample_tensor(r3d_ctx *ctx, const double *xyz, const double *colors, const double *normals, int64_t n, double voxel,
                                 double *out_xyz, double *out_colors, double *out_normals, int64_t *out_n) {
+    R3D_ROCTX_RANGE("r3d_voxel_downsample_tensor");
     return voxel_downsample_impl(ctx, xyz, colors, normals, n, voxel, out_xyz, out_colors, out_normals, out_n, true);
 }
 
@@ -1849,6 +1851,7 @@ static int voxel_downsample_impl(r3d_ctx *ctx, const double *xyz, const double *
 
 int r3d_estimate_normals(r3d_ctx *ctx, const double *xyz, int64_t n, double radius, int32_t max_nn, const double *prev_normals,
                          double *normals) {
+    R3D_ROCTX_RANGE("r3d_estimate_normals");
     if (!ctx) return R3D_E_BADARG;
     if (!xyz || !normals || n <= 0 || max_nn < 1) return r3d_fail(ctx, R3D_E_BADARG, "estimate_normals: bad argument");
     if (max_nn > 128) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "estimate_normals: max_nn > 128 not supported");
@@ -1865,6 +1868,7 @@ int r3d_estimate_normals(r3d_ctx *ctx, const double *xyz, int64_t n, double radi
 }
 
 int r3d_neighbor_score(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, double count_radius, double *score) {
+    R3D_ROCTX_RANGE("r3d_neighbor_score");
     if (!ctx) return R3D_E_BADARG;
     if (!xyz || !score || n <= 0 || (count_radius <= 0 && k < 1)) return r3d_fail(ctx, R3D_E_BADARG, "neighbor_score: bad argument");
     if (k > 128) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "neighbor_score: k > 128 not supported");
@@ -1889,6 +1893,7 @@ int r3d_neighbor_score(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, do
 
 int r3d_reproject_disparity(r3d_ctx *ctx, const int16_t *disp, int32_t w, int32_t h, const double *Q4x4, int32_t min_valid_x16,
                             double *out_xyz, int32_t *out_pixel, int64_t *out_n) {
+    R3D_ROCTX_RANGE("r3d_reproject_disparity");
     if (!ctx) return R3D_E_BADARG;
     if (!disp || !Q4x4 || !out_xyz || !out_n || w <= 0 || h <= 0) return r3d_fail(ctx, R3D_E_BADARG, "reproject_disparity: bad argument");
     R3D_HIP(ctx, hipSetDevice(ctx->device));
@@ -1960,6 +1965,7 @@ static int disparity_to_cloud_impl(r3d_ctx *ctx, const int16_t *d_disp, int32_t 
 int r3d_disparity_to_cloud_dev(r3d_ctx *ctx, const int16_t *d_disp, int32_t w, int32_t h, const double *Q4x4, int32_t min_valid_x16,
                                double max_depth, const double *pose4x4, double voxel, double normal_radius, int32_t max_nn,
                                int64_t capacity, double *out_xyz, double *out_normals, int64_t *out_n) {
+    R3D_ROCTX_RANGE("r3d_disparity_to_cloud_dev");
     return disparity_to_cloud_impl(ctx, d_disp, w, h, Q4x4, min_valid_x16, max_depth, pose4x4, voxel, normal_radius, max_nn, capacity,
                                    out_xyz, out_normals, out_n, false);
 }
@@ -1967,6 +1973,7 @@ int r3d_disparity_to_cloud_dev(r3d_ctx *ctx, const int16_t *d_disp, int32_t w, i
 int r3d_disparity_to_cloud_resident(r3d_ctx *ctx, const int16_t *d_disp, int32_t w, int32_t h, const double *Q4x4, int32_t min_valid_x16,
                                     double max_depth, const double *pose4x4, double voxel, double normal_radius, int32_t max_nn,
                                     int64_t capacity, double *d_out_xyz, double *d_out_normals, int64_t *out_n) {
+    R3D_ROCTX_RANGE("r3d_disparity_to_cloud_resident");
     return disparity_to_cloud_impl(ctx, d_disp, w, h, Q4x4, min_valid_x16, max_depth, pose4x4, voxel, normal_radius, max_nn, capacity,
                                    d_out_xyz, d_out_normals, out_n, true);
 }
@@ -1974,6 +1981,7 @@ int r3d_disparity_to_cloud_resident(r3d_ctx *ctx, const int16_t *d_disp, int32_t
 int r3d_align_point_clouds(r3d_ctx *ctx, const r3d_align_params *p, const double *src, const double *src_colors, int64_t ns,
                            const double *tgt, int64_t nt, const double *init4x4, double *out_xyz, double *out_colors,
                            double *out_normals, int64_t *out_n, double *T4x4, r3d_icp_stats *stats) {
+    R3D_ROCTX_RANGE("r3d_align_point_clouds");
     if (!ctx) return R3D_E_BADARG;
     if (!p || !src || !tgt || !out_xyz || !out_n || !T4x4 || ns <= 0 || nt <= 0) return r3d_fail(ctx, R3D_E_BADARG, "align: bad argument");
     if (src_colors && !out_colors) return r3d_fail(ctx, R3D_E_BADARG, "align: colours given without an output array");
@@ -2035,6 +2043,7 @@ int r3d_align_point_clouds(r3d_ctx *ctx, const r3d_align_params *p, const double
 }
 
 int r3d_knn_graph(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, double radius, int32_t *nbr, double *d2) {
+    R3D_ROCTX_RANGE("r3d_knn_graph");
     if (!ctx) return R3D_E_BADARG;
     if (!xyz || !nbr || n <= 0 || k < 1) return r3d_fail(ctx, R3D_E_BADARG, "knn_graph: bad argument");
     if (k > 128) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "knn_graph: k > 128 not supported");
@@ -2193,6 +2202,7 @@ int orient_core(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, const int
 extern "C" {
 
 int r3d_orient_normals(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, double *normals) {
+    R3D_ROCTX_RANGE("r3d_orient_normals");
     if (!ctx) return R3D_E_BADARG;
     if (!xyz || !normals || n <= 0 || k < 1) return r3d_fail(ctx, R3D_E_BADARG, "orient_normals: bad argument");
     if (n == 1) { if (normals[2] < 0) for (int a = 0; a < 3; a++) normals[a] = -normals[a]; return R3D_OK; }
@@ -2201,6 +2211,7 @@ int r3d_orient_normals(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, do
 
 int r3d_orient_normals_graph(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t k, const int32_t *delaunay_edges, int64_t n_edges,
                              double *normals) {
+    R3D_ROCTX_RANGE("r3d_orient_normals_graph");
     if (!ctx) return R3D_E_BADARG;
     if (!xyz || !normals || !delaunay_edges || n <= 0 || k < 1 || n_edges < 0) return r3d_fail(ctx, R3D_E_BADARG, "orient_normals_graph: bad argument");
     if (n < 4) return r3d_fail(ctx, R3D_E_BADARG, "orient_normals_graph: a tetrahedralisation needs at least 4 points");
@@ -2208,6 +2219,7 @@ int r3d_orient_normals_graph(r3d_ctx *ctx, const double *xyz, int64_t n, int32_t
 }
 
 int r3d_transform_points(r3d_ctx *ctx, const double *xyz, int64_t n, const double *T4x4, int32_t rotate_only, double *out) {
+    R3D_ROCTX_RANGE("r3d_transform_points");
     if (!ctx) return R3D_E_BADARG;
     if (!xyz || !out || !T4x4 || n <= 0) return r3d_fail(ctx, R3D_E_BADARG, "transform_points: bad argument");
     R3D_HIP(ctx, hipSetDevice(ctx->device));
@@ -2226,6 +2238,7 @@ int r3d_transform_points(r3d_ctx *ctx, const double *xyz, int64_t n, const doubl
 
 int r3d_icp(r3d_ctx *ctx, const r3d_icp_params *p, const double *src, int64_t ns, const double *src_normals, const double *tgt,
             int64_t nt, const double *tgt_normals, const double *init4x4, double *T4x4, r3d_icp_stats *stats) {
+    R3D_ROCTX_RANGE("r3d_icp");
     if (!ctx) return R3D_E_BADARG;
     if (!p || !src || !tgt || !T4x4 || ns <= 0 || nt <= 0) return r3d_fail(ctx, R3D_E_BADARG, "icp: bad argument");
     if (p->mode < 0 || p->mode > 2) return r3d_fail(ctx, R3D_E_BADARG, "icp: mode must be 0 (P2P), 1 (P2PLANE) or 2 (GICP)");
@@ -2334,6 +2347,7 @@ int r3d_model_size(r3d_model *m, int64_t *n, int32_t *has_colors, int32_t *has_n
 }
 
 int r3d_model_append(r3d_model *m, const double *xyz, const double *colors, const double *normals, int64_t n) {
+    R3D_ROCTX_RANGE("r3d_model_append");
     if (!m) return R3D_E_BADARG;
     r3d_ctx *ctx = m->ctx;
     if (!xyz || n < 0) return r3d_fail(ctx, R3D_E_BADARG, "model_append: bad argument");
@@ -2344,6 +2358,7 @@ int r3d_model_append(r3d_model *m, const double *xyz, const double *colors, cons
 
 int r3d_model_align_append(r3d_model *m, const r3d_align_params *p, const double *src, const double *src_colors, int64_t ns,
                            double *T4x4, r3d_icp_stats *stats, int64_t *appended) {
+    R3D_ROCTX_RANGE("r3d_model_align_append");
     if (!m) return R3D_E_BADARG;
     r3d_ctx *ctx = m->ctx;
     if (!p || !src || !T4x4 || ns <= 0) return r3d_fail(ctx, R3D_E_BADARG, "model_align_append: bad argument");
@@ -2404,6 +2419,7 @@ int r3d_model_align_append(r3d_model *m, const r3d_align_params *p, const double
 
 int r3d_model_register_append(r3d_model *m, const r3d_icp_params *p, const double *src, const double *src_colors, const double *src_normals,
                               int64_t ns, double *T4x4, r3d_icp_stats *stats) {
+    R3D_ROCTX_RANGE("r3d_model_register_append");
     if (!m) return R3D_E_BADARG;
     r3d_ctx *ctx = m->ctx;
     if (!p || !src || !T4x4 || ns <= 0) return r3d_fail(ctx, R3D_E_BADARG, "model_register_append: bad argument");
@@ -2434,6 +2450,7 @@ int r3d_model_register_append(r3d_model *m, const r3d_icp_params *p, const doubl
 }
 
 int r3d_model_estimate_normals(r3d_model *m, double radius, int32_t max_nn) {
+    R3D_ROCTX_RANGE("r3d_model_estimate_normals");
     if (!m) return R3D_E_BADARG;
     r3d_ctx *ctx = m->ctx;
     if (max_nn < 1) return r3d_fail(ctx, R3D_E_BADARG, "model_estimate_normals: bad argument");
@@ -2452,6 +2469,7 @@ int r3d_model_estimate_normals(r3d_model *m, double radius, int32_t max_nn) {
 }
 
 int r3d_model_download(r3d_model *m, double *xyz, double *colors, double *normals) {
+    R3D_ROCTX_RANGE("r3d_model_download");
     if (!m) return R3D_E_BADARG;
     r3d_ctx *ctx = m->ctx;
     if (!xyz) return r3d_fail(ctx, R3D_E_BADARG, "model_download: bad argument");
@@ -2470,6 +2488,7 @@ int r3d_model_download(r3d_model *m, double *xyz, double *colors, double *normal
 // asynchronous.
 int r3d_icp_dev(r3d_ctx *ctx, const r3d_icp_params *p, const double *d_src, int64_t ns, const double *d_src_normals, const double *d_tgt,
                 int64_t nt, const double *d_tgt_normals, const double *init4x4, double *T4x4, r3d_icp_stats *stats) {
+    R3D_ROCTX_RANGE("r3d_icp_dev");
     if (!ctx) return R3D_E_BADARG;
     if (!p || !d_src || !d_tgt || !T4x4 || ns <= 0 || nt <= 0) return r3d_fail(ctx, R3D_E_BADARG, "icp_dev: bad argument");
     if (p->mode < 0 || p->mode > 2) return r3d_fail(ctx, R3D_E_BADARG, "icp_dev: mode must be 0 (P2P), 1 (P2PLANE) or 2 (GICP)");
@@ -2484,6 +2503,7 @@ int r3d_icp_dev(r3d_ctx *ctx, const r3d_icp_params *p, const double *d_src, int6
 }
 
 int r3d_transform_points_dev(r3d_ctx *ctx, const double *d_xyz, int64_t n, const double *T4x4, int32_t rotate_only, double *d_out) {
+    R3D_ROCTX_RANGE("r3d_transform_points_dev");
     if (!ctx) return R3D_E_BADARG;
     if (!d_xyz || !d_out || !T4x4 || n < 0) return r3d_fail(ctx, R3D_E_BADARG, "transform_points_dev: bad argument");
     if (n == 0) return R3D_OK;

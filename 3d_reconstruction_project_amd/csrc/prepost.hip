@@ -809,6 +809,7 @@ int check_ctx(r3d_ctx *ctx) {
 extern "C" int r3d_init_undistort_rectify_map(r3d_ctx *ctx, const double *camera3x3, const double *dist, int32_t n_dist,
                                               const double *R3x3, const double *new_camera, int32_t new_camera_cols, int32_t w,
                                               int32_t h, int16_t *map1, uint16_t *map2) {
+    R3D_ROCTX_RANGE("r3d_init_undistort_rectify_map");
     if (check_ctx(ctx)) return R3D_E_BADARG;
     if (!camera3x3 || !new_camera || !map1 || !map2 || w <= 0 || h <= 0 || (new_camera_cols != 3 && new_camera_cols != 4))
         return r3d_fail(ctx, R3D_E_BADARG, "init_undistort_rectify_map: bad argument");
@@ -863,6 +864,7 @@ extern "C" int r3d_init_undistort_rectify_map(r3d_ctx *ctx, const double *camera
 extern "C" int r3d_remap_u8_dev(r3d_ctx *ctx, const uint8_t *d_src, int32_t sw, int32_t sh, int32_t sstride, int32_t cn,
                                 const int16_t *d_map1, const uint16_t *d_map2, int32_t dw, int32_t dh, int32_t border_value,
                                 uint8_t *d_dst, uint8_t *d_gray) {
+    R3D_ROCTX_RANGE("r3d_remap_u8_dev");
     if (check_ctx(ctx)) return R3D_E_BADARG;
     if (!d_src || !d_map1 || !d_map2 || !d_dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || sstride < sw * cn)
         return r3d_fail(ctx, R3D_E_BADARG, "remap: bad argument");
@@ -880,6 +882,7 @@ extern "C" int r3d_remap_u8_dev(r3d_ctx *ctx, const uint8_t *d_src, int32_t sw, 
 extern "C" int r3d_remap_u8(r3d_ctx *ctx, const uint8_t *src, int32_t sw, int32_t sh, int32_t sstride, int32_t cn,
                             const int16_t *map1, const uint16_t *map2, int32_t dw, int32_t dh, int32_t border_value, uint8_t *dst,
                             uint8_t *gray) {
+    R3D_ROCTX_RANGE("r3d_remap_u8");
     if (check_ctx(ctx)) return R3D_E_BADARG;
     if (!src || !map1 || !map2 || !dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || cn < 1 || cn > 4 || sstride < sw * cn)
         return r3d_fail(ctx, R3D_E_BADARG, "remap: bad argument");
@@ -901,6 +904,7 @@ extern "C" int r3d_remap_u8(r3d_ctx *ctx, const uint8_t *src, int32_t sw, int32_
 }
 
 extern "C" int r3d_bgr2gray_dev(r3d_ctx *ctx, const uint8_t *d_bgr, int32_t w, int32_t h, int32_t stride, int32_t cn, uint8_t *d_gray) {
+    R3D_ROCTX_RANGE("r3d_bgr2gray_dev");
     if (check_ctx(ctx)) return R3D_E_BADARG;
     if (!d_bgr || !d_gray || w <= 0 || h <= 0 || (cn != 3 && cn != 4) || stride < w * cn || h > 65535)
         return r3d_fail(ctx, R3D_E_BADARG, "bgr2gray: bad argument");
@@ -910,6 +914,7 @@ extern "C" int r3d_bgr2gray_dev(r3d_ctx *ctx, const uint8_t *d_bgr, int32_t w, i
 }
 
 extern "C" int r3d_bgr2gray(r3d_ctx *ctx, const uint8_t *bgr, int32_t w, int32_t h, int32_t stride, int32_t cn, uint8_t *gray) {
+    R3D_ROCTX_RANGE("r3d_bgr2gray");
     if (check_ctx(ctx)) return R3D_E_BADARG;
     if (!bgr || !gray || w <= 0 || h <= 0 || (cn != 3 && cn != 4) || stride < w * cn) return r3d_fail(ctx, R3D_E_BADARG, "bgr2gray: bad argument");
     PPArena ar(ctx);
@@ -925,6 +930,7 @@ extern "C" int r3d_bgr2gray(r3d_ctx *ctx, const uint8_t *bgr, int32_t w, int32_t
 }
 
 extern "C" int r3d_normalize_minmax_s16_dev(r3d_ctx *ctx, const int16_t *d_src, int64_t n, double alpha, double beta, int16_t *d_dst) {
+    R3D_ROCTX_RANGE("r3d_normalize_minmax_s16_dev");
     if (check_ctx(ctx)) return R3D_E_BADARG;
     if (!d_src || !d_dst || n <= 0) return r3d_fail(ctx, R3D_E_BADARG, "normalize: bad argument");
     r3d_buf &mmb = ctx->pp_minmax;
@@ -940,6 +946,7 @@ extern "C" int r3d_normalize_minmax_s16_dev(r3d_ctx *ctx, const int16_t *d_src, 
 }
 
 extern "C" int r3d_normalize_minmax_s16(r3d_ctx *ctx, const int16_t *src, int64_t n, double alpha, double beta, int16_t *dst) {
+    R3D_ROCTX_RANGE("r3d_normalize_minmax_s16");
     if (check_ctx(ctx)) return R3D_E_BADARG;
     if (!src || !dst || n <= 0) return r3d_fail(ctx, R3D_E_BADARG, "normalize: bad argument");
     PPArena ar(ctx);
@@ -1053,6 +1060,7 @@ static int wls_check(r3d_ctx *ctx, const r3d_wls_params *p, int gcn, int w, int 
 extern "C" int r3d_wls_filter_dev(r3d_ctx *ctx, const r3d_wls_params *p, const int16_t *d_disp_left, const int16_t *d_disp_right,
                                   const uint8_t *d_guide, int32_t guide_cn, int32_t guide_stride, int32_t w, int32_t h,
                                   int16_t *d_out, float *d_confidence) {
+    R3D_ROCTX_RANGE("r3d_wls_filter_dev");
     if (check_ctx(ctx)) return R3D_E_BADARG;
     int rc = wls_check(ctx, p, guide_cn, w, h);
     if (rc) return rc;
@@ -1065,6 +1073,7 @@ extern "C" int r3d_wls_filter_dev(r3d_ctx *ctx, const r3d_wls_params *p, const i
 extern "C" int r3d_wls_filter(r3d_ctx *ctx, const r3d_wls_params *p, const int16_t *disp_left, const int16_t *disp_right,
                               const uint8_t *guide, int32_t guide_cn, int32_t guide_stride, int32_t w, int32_t h, int16_t *out,
                               float *confidence) {
+    R3D_ROCTX_RANGE("r3d_wls_filter");
     if (check_ctx(ctx)) return R3D_E_BADARG;
     int rc = wls_check(ctx, p, guide_cn, w, h);
     if (rc) return rc;

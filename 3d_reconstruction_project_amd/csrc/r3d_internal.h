@@ -108,6 +108,20 @@ static inline void r3d_prof_end(r3d_ctx *ctx, r3d_sgm_ws &ws, hipStream_t st) {
     ps.pending = true;
 }
 
+
+// roctx ranges around every C-ABI entry point ("rocprofv3 --marker-trace attributes kernels to entry
+// points").  The marker library is looked up at run time (librocprofiler-sdk-roctx.so, the one rocprofv3 listens to, else the
+// legacy libroctx64.so); without it, or with R3D_ROCTX=0, a range is two predictable branches.
+void r3d_roctx_push(const char *name);
+void r3d_roctx_pop();
+struct r3d_roctx_scope {
+    explicit r3d_roctx_scope(const char *name) { r3d_roctx_push(name); }
+    ~r3d_roctx_scope() { r3d_roctx_pop(); }
+    r3d_roctx_scope(const r3d_roctx_scope &) = delete;
+    r3d_roctx_scope &operator=(const r3d_roctx_scope &) = delete;
+};
+#define R3D_ROCTX_RANGE(name) r3d_roctx_scope r3d_roctx_scope_(name)
+
 // sgm.hip
 int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p, const uint8_t *d_left, const uint8_t *d_right,
                 int w, int h, int stride, int16_t *d_disp);

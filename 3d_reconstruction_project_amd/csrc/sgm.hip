@@ -970,6 +970,87 @@ __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// k_hscan_fwd: phase 1 of k_hscan2 (forward chain + checkpoints) as a LOW-REGISTER kernel of its own, for the overlap with the
+// cost kernel.  k_hscan2 keeps 256 + 128 registers of cost segments in flight and owns the whole register file of its SIMD, so
+// none of its waves can start while cost waves occupy that SIMD (measured: cost and a k_hscan2<PHASE 1> launch on two streams
+// simply ran one after the other).  Here the rotating buffers hold K = 4 columns (64 registers), the kernel is compiled for
+// four waves per SIMD (<= 128 registers) and fits beside the two cost workgroups a CU holds (4 x 96 registers per SIMD).
+// Segments [seg0, seg1) are counted in checkpoint intervals of KCK columns (the K of the backward-phase kernel that reads the
+// checkpoints); the state entering seg0 comes from the previous launch, the state entering seg1 is left for the next one; the
+// launch that reaches the last interval also runs the tail columns (parked in the output row, as k_hscan2 does).
+template <int NPL, int LPC, int K, int KCK, bool PADDED>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_hscan_fwd(const int *__restrict__ cvol, int *__restrict__ hvol, int *__restrict__ ckpt, SgmGeom g, int seg0, int seg1) {
+    static_assert(KCK % K == 0, "checkpoint interval is a whole number of buffer segments");
+    constexpr int DPW = NPL * LPC, RPW = 64 / LPC, CKW = (NPL + 1) * 64, RATIO = KCK / K;
+    const int lane = threadIdx.x, k = lane % LPC;
+    const int yraw = blockIdx.x * RPW + lane / LPC;
+    const bool row_ok = yraw < g.H;
+    const int y = min(yraw, g.H - 1);
+    const int *crow = cvol + (size_t)y * g.W1 * DPW + k * NPL;
+    int *hrow = hvol + (size_t)y * g.W1 * DPW + k * NPL;
+    const int W1 = g.W1, nck = W1 / KCK, P1pk = pk_dup(g.P1);
+    int *ck = ckpt + (size_t)blockIdx.x * (nck + 1) * CKW + lane * (NPL + 1);
+    const bool valid = 2 * NPL * k < g.D, first = k == 0, last = k == LPC - 1;
+    const int ck_lo = max(seg0, 0), ck_hi = min(seg1, nck);
+    const int sb = ck_lo * RATIO, se = ck_hi * RATIO;          // sub-segments of K columns
+    int P[NPL], minp = 0;
+    if (ck_lo > 0) {
+#pragma unroll
+        for (int j = 0; j < NPL; j++) P[j] = ck[(size_t)ck_lo * CKW + j];
+        minp = ck[(size_t)ck_lo * CKW + NPL];
+    } else {
+#pragma unroll
+        for (int j = 0; j < NPL; j++) P[j] = valid ? 0 : PADPK;
+    }
+    int c0[K][NPL], c1[K][NPL], c2[K][NPL], c3[K][NPL];
+    auto load_seg = [&](int (&buf)[K][NPL], int sidx) {        // never reads past this launch's slab
+        const int sc = min(max(sidx, 0), max(se - 1, 0));
+        const int *p = crow + (size_t)sc * K * DPW;
+#pragma unroll
+        for (int u = 0; u < K; u++)
+#pragma unroll
+            for (int j = 0; j < NPL; j++) buf[u][j] = p[(size_t)u * DPW + j];
+    };
+    auto round = [&](int (&cur)[K][NPL], int (&pre)[K][NPL], int sidx) {
+        load_seg(pre, sidx + 3);
+        if (sidx % RATIO == 0) {
+#pragma unroll
+            for (int j = 0; j < NPL; j++) ck[(size_t)(sidx / RATIO) * CKW + j] = P[j];
+            ck[(size_t)(sidx / RATIO) * CKW + NPL] = minp;
+        }
+#pragma unroll
+        for (int u = 0; u < K; u++) sgm_step_g<NPL, LPC, PADDED>(P, minp, cur[u], P1pk, g.P2, first, last, valid);
+    };
+    if (se > sb) {
+        load_seg(c0, sb); load_seg(c1, sb + 1); load_seg(c2, sb + 2);
+#pragma unroll 1
+        for (int s0 = sb; s0 < se; s0 += 4) {
+            round(c0, c3, s0);
+            if (s0 + 1 < se) round(c1, c0, s0 + 1);
+            if (s0 + 2 < se) round(c2, c1, s0 + 2);
+            if (s0 + 3 < se) round(c3, c2, s0 + 3);
+        }
+    }
+    if (ck_hi < nck) {                                          // state entering the next launch's first interval
+#pragma unroll
+        for (int j = 0; j < NPL; j++) ck[(size_t)ck_hi * CKW + j] = P[j];
+        ck[(size_t)ck_hi * CKW + NPL] = minp;
+        return;
+    }
+    for (int x = nck * KCK; x < W1; x++) {                      // tail columns: forward values parked in the output row
+        int c[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; j++) c[j] = crow[(size_t)x * DPW + j];
+        sgm_step_g<NPL, LPC, PADDED>(P, minp, c, P1pk, g.P2, first, last, valid);
+        if (row_ok) {
+#pragma unroll
+            for (int j = 0; j < NPL; j++) hrow[(size_t)x * DPW + j] = P[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Winner-take-all + uniqueness + sub-pixel for one disparity vector in the generic mapping (group-uniform results).
 // sS: per-wave LDS image (64 * NPL ints) used to fetch the winner's two neighbours with a per-group address.
 template <int NPL, int LPC>
@@ -1900,6 +1981,8 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
     static const int n_slabs = [] { const char *e = getenv("R3D_SGM_OVERLAP"); const int v = e ? atoi(e) : 4; return v < 2 ? 0 : (v > R3D_SGM_SLABS ? R3D_SGM_SLABS : v); }();
     static const bool rows2_env = [] { const char *e = getenv("R3D_HSCAN_ROWS"); return e && !strcmp(e, "2"); }();
     constexpr int KOV = 16;
+    // R3D_SGM_FWD=wide: the forward launches use k_hscan2<PHASE 1> (whole register file: cannot share a SIMD with cost waves)
+    static const bool lowreg = [] { const char *e = getenv("R3D_SGM_FWD"); return !(e && !strcmp(e, "wide")); }();
     const bool track = (long)(2 * g.SH2 + 1) * (2 * g.SH2 + 1) * (2L * g.ftzero + 63) > 16383;
     const bool overlapped = !use_v1 && n_slabs >= 2 && g.DP == 128 && !rows2_env && !track && g.W1 / KOV >= 8 * n_slabs;
     if (overlapped) {
@@ -1926,8 +2009,13 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
         for (int j = 0; j < n_slabs; j++) {
             const int seg_hi = j == n_slabs - 1 ? nfull : (int)((long)nfull * (j + 1) / n_slabs);
             R3D_HIP(ctx, hipStreamWaitEvent(st, ws.slab_ev[j], 0));
-            if (padded) k_hscan2<4, 16, KOV, true, 1><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, seg_lo, seg_hi);
-            else k_hscan2<4, 16, KOV, false, 1><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, seg_lo, seg_hi);
+            if (lowreg) {
+                if (padded) k_hscan_fwd<4, 16, 4, KOV, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, seg_lo, seg_hi);
+                else k_hscan_fwd<4, 16, 4, KOV, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, seg_lo, seg_hi);
+            } else {
+                if (padded) k_hscan2<4, 16, KOV, true, 1><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, seg_lo, seg_hi);
+                else k_hscan2<4, 16, KOV, false, 1><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, seg_lo, seg_hi);
+            }
             seg_lo = seg_hi;
         }
         R3D_HIP(ctx, hipGetLastError());

@@ -306,8 +306,17 @@ typedef struct r3d_wls_params {
     int32_t num_iter;              /* 3 */
     int32_t solver;                /* R3D_WLS_SOLVER_*: how the smoother's tridiagonal systems are solved */
 } r3d_wls_params;
-#define R3D_WLS_SOLVER_PARTITIONED 0 /* block-parallel (31-unknown blocks + Schur complement over separators); default */
-#define R3D_WLS_SOLVER_SEQUENTIAL 1  /* one Thomas sweep per line, the operation order of the CPU original; slow */
+/* CONTRACT of the two solvers (tests/test_prepost_gpu.py asserts it up to 3264x2448, D = 128):
+ *   R3D_WLS_SOLVER_SEQUENTIAL  one Thomas sweep per line in the float32 operation order of the CPU original as restated in
+ *       oracle/prepost_oracle.py: confidence map and filtered map BIT-EXACT against that restatement.  39 waves on a
+ *       1024-SIMD chip: 7.8 ms per 8 MP frame.
+ *   R3D_WLS_SOLVER_PARTITIONED (default)  solves the SAME tridiagonal systems block-parallel (31-unknown blocks + Schur
+ *       complement over the separators): exact in exact arithmetic, a different float32 rounding order.  TOLERANCE: the
+ *       confidence map is bit-exact; the filtered int16 map (x16 fixed point) differs from the sequential solver's by AT MOST
+ *       1 LSB (1/16 px) on FEWER THAN 0.1 % of the pixels (a value that rounds half-to-even differently), and not at all
+ *       outside the ROI.  0.69 ms per 8 MP frame.  Callers that need the bit-exact map select the sequential solver. */
+#define R3D_WLS_SOLVER_PARTITIONED 0
+#define R3D_WLS_SOLVER_SEQUENTIAL 1
 /* disp_left / disp_right: int16 x16 maps of the left and the right matcher (the right one holds negative values);
  * guide: uint8 left view with guide_cn = 1 or 3 channels.  out: int16 x16, 16*(minD-1) outside the ROI.
  * confidence (may be NULL): float [h][w] map in [0,255] (getConfidenceMap()). */

@@ -345,8 +345,17 @@ def orient_normals(points, normals, k, edges=None, delaunay_blocks_knn=True):
 
 
 # ----------------------------------------------------------------------------------------------- registration
-def transform_points(T, p):
-    return p @ T[:3, :3].T + T[:3, 3]
+def transform_points(T, p, rotate_only=False):
+    """PointCloud::Transform (pointcloud_alignment.py:42).  Written out per coordinate as ((r0 x + r1 y) + r2 z) + t, without
+    fused multiply-adds: the order Eigen uses for a 4x4 times a point is an implementation detail of the original; fixing one
+    here (the HIP kernel's) keeps the loops that feed a transformed cloud back into a neighbour search comparable bit for bit
+    instead of up to rounding (an ill-conditioned PCA normal amplifies a 1e-16 coordinate difference to 1e-2)."""
+    T = np.asarray(T, float)
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    out = np.empty_like(p, dtype=float)
+    for i in range(3):
+        out[:, i] = ((T[i, 0] * x + T[i, 1] * y) + T[i, 2] * z) + (0.0 if rotate_only else T[i, 3])
+    return out
 
 
 def euler_zyx_to_matrix(x6):
@@ -496,7 +505,7 @@ def fuse_loop(frames, flavour="icp", threshold=0.02, voxel_size=0.01, max_iter=1
                                target_cov=covariances_from_normals(model_n), source_cov=covariances_from_normals(fn))
             T = res["T"]
             model = np.concatenate([model, transform_points(T, fp)], 0)
-            model_n = np.concatenate([model_n, fn @ T[:3, :3].T], 0)
+            model_n = np.concatenate([model_n, transform_points(T, fn, rotate_only=True)], 0)
             model_n = estimate_normals_hybrid(model, 0.05, 30, prev_normals=model_n)
         if log is not None:
             log.append(res)

@@ -52,20 +52,46 @@ def test_fuse_loop_icp_flavour_all_eight_c4_frames(r3d):
 def test_fuse_loop_gicp_flavour_all_eight_c4_frames(r3d):
     """BASELINE config C4, test/GICP1.py:134-155 flavour: frames are tensor-voxel-down-sampled (:71-72) and carry
     Hybrid(0.05, 30) normals (:77); every later frame is registered to the WHOLE model with registration_generalized_icp
-    (:99-102), appended with its normals, and the model's normals are re-estimated (:148) keeping their orientation."""
+    (:99-102), appended with its normals, and the model's normals are re-estimated (:148) keeping their orientation.
+    Every one of the seven steps is checked against the oracle FROM THE SAME MODEL STATE (the model is downloaded before each
+    frame): iteration count, fitness, RMSE, transform, appended points, re-estimated normals.  A free-running comparison of the
+    final clouds is not a parity statement for this flavour: the loop stops on |d fitness| < 1e-6, i.e. on an unchanged inlier
+    COUNT, so a 1e-13 difference in one ill-conditioned normal moves the stop by five iterations at frame 10 and the last
+    frame (fitness 0.58, never converges) amplifies that to millimetres -- on the oracle run against itself just as well."""
     frames = []
     for f in _c4_frames():
         p = co.voxel_down_sample_tensor(f, 0.01)
         frames.append((p, co.estimate_normals_hybrid(p, 0.05, 30)))
+    model = r3d.cloud_ops.ResidentModel()
+    model.append(frames[0][0], None, frames[0][1])
+    for p, n in frames[1:]:
+        mp, _, mn = model.download()
+        want = co.registration(p, mp, 0.02, mode="gicp", max_iteration=30, target_normals=mn,
+                               target_cov=co.covariances_from_normals(mn), source_cov=co.covariances_from_normals(n))
+        got = model.register_append(p, 0.02, r3d.cloud_ops.GICP, 30, source_normals=n)
+        assert got["iterations"] == want["iterations"] and got["correspondences"] == want["correspondences"]
+        assert abs(got["fitness"] - want["fitness"]) < 1e-12 and abs(got["inlier_rmse"] - want["inlier_rmse"]) < 1e-9
+        assert np.abs(got["T"] - want["T"]).max() < 1e-8                                  # bar: 1e-3
+        model.estimate_normals(0.05, 30)
+        mp2, _, mn2 = model.download()
+        assert len(mp2) == len(mp) + len(p)
+        np.testing.assert_array_equal(mp2[:len(mp)], mp)
+        assert np.abs(mp2[len(mp):] - co.transform_points(want["T"], p)).max() < 1e-8     # bar: 1e-3
+        prev = np.concatenate([mn, co.transform_points(got["T"], n, rotate_only=True)])
+        want_n, covs = co._pca_normals(mp2, co.hybrid_neighbors(mp2, 0.05, 30), prev)
+        err = np.abs(mn2 - want_n).max(1)
+        # a normal is defined up to the separation of the two smallest eigenvalues of its covariance: where they (nearly)
+        # coincide (collinear neighbours at the rim of a depth image) its direction is noise on BOTH sides
+        w = np.linalg.eigvalsh(covs)
+        gap = (w[:, 1] - w[:, 0]) / np.maximum(w[:, 2], 1e-300)
+        loose = err > 1e-6
+        assert loose.mean() < 1e-3 and (gap[loose] < 1e-6).all() and err[gap > 1e-6].max() < 1e-6
+    final = model.download()
+    model.close()
+    # the loop function drives exactly these calls
     got = r3d.pipeline.fuse([r3d.PointCloud(p, normals=n) for p, n in frames], flavour="gicp")
-    log = []
-    want_p, want_n = co.fuse_loop(frames, "gicp", threshold=0.02, log=log)
-    assert got.points.shape == want_p.shape and got.has_normals() and len(log) == 7
-    assert np.abs(got.points - want_p).max() < 1e-6                    # bar: 1e-3
-    # normals: 1e-3 bar; a normal whose two smallest eigenvalues nearly coincide amplifies the 1e-9 coordinate differences,
-    # so the bound is stated on all points at the bar and on the bulk far below it
-    err = np.abs(got.normals - want_n).max(1)
-    assert err.max() < 1e-3 and np.quantile(err, 0.999) < 1e-6
+    np.testing.assert_array_equal(got.points, final[0])
+    np.testing.assert_array_equal(got.normals, final[2])
 
 
 def test_resident_model_loop_equals_host_model_loop(r3d):

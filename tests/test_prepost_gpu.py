@@ -127,6 +127,25 @@ def test_wls_filter_vs_oracle(r3d, synth, W, H, D, guide_cn):
     np.testing.assert_array_equal(wls.filter(dl, guide, None, dr), want)
 
 
+def test_wls_filter_documented_bound_at_8mp(r3d, synth):
+    """The contract of R3D_WLS_SOLVER_PARTITIONED written in include/r3d.h (depth2.py:164-166,255 at the C2 frame size): the
+    confidence map is bit-exact; the filtered int16 map differs from the sequential float32 operation order (the oracle's, and
+    R3D_WLS_SOLVER_SEQUENTIAL's) by at most 1 LSB (1/16 px) on fewer than 0.1 % of the pixels, never outside the ROI."""
+    W, H, D = 3264, 2448, 128
+    L, R, _ = synth.stereo_pair(W, H, D, seed=5)
+    dl, dr, wls = _disparities(r3d, L, R, D)
+    wls.setLambda(8000)
+    wls.setSigmaColor(1.5)
+    want, wconf = _po().wls_filter(dl, L, dr, 0, D, 5, lam=8000, sigma_color=1.5, return_confidence=True)
+    got = wls.filter(dl, L, None, dr)
+    np.testing.assert_array_equal(wls.getConfidenceMap(), wconf)
+    diff = np.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+    assert (diff[:, :D] == 0).all()
+    wls.solver = r3d.stereo_prepost.SOLVER_SEQUENTIAL
+    np.testing.assert_array_equal(wls.filter(dl, L, None, dr), want)
+
+
 def test_wls_negative_min_disparity_roi_and_accessors(r3d, synth):
     W, H, D, minD = 300, 90, 32, -8
     L, R, _ = synth.stereo_pair(W, H, D + minD, seed=9)
