@@ -982,6 +982,8 @@ template <int NPL, int LPC, int K, int KCK, bool PADDED>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_hscan_fwd(const int *__restrict__ cvol, int *__restrict__ hvol, int *__restrict__ ckpt, SgmGeom g, int seg0, int seg1) {
     static_assert(KCK % K == 0, "checkpoint interval is a whole number of buffer segments");
+    // (Raising this wave's issue priority with s_setprio 3 was tried: the cost slabs then took 313 us instead of 200-295 and
+    // the forward slabs stayed at 200-430 us: the slowdown is in the memory system, not in the issue arbiter.)
     constexpr int DPW = NPL * LPC, RPW = 64 / LPC, CKW = (NPL + 1) * 64, RATIO = KCK / K;
     const int lane = threadIdx.x, k = lane % LPC;
     const int yraw = blockIdx.x * RPW + lane / LPC;
@@ -1971,14 +1973,19 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
         }
         R3D_HIP(ctx, hipGetLastError());
     }
-    // Column-slab overlap of the cost kernel with the forward phase of the horizontal scan (R3D_SGM_OVERLAP = number of slabs,
-    // default 4; 0 or 1: one kernel after the other).  The forward chain at column x only needs C of columns <= x, so the
+    // Column-slab overlap of the cost kernel with the forward phase of the horizontal scan (R3D_SGM_OVERLAP = number of slabs;
+    // DEFAULT OFF: measured slower, see below).  The forward chain at column x only needs C of columns <= x, so the
     // cost kernel runs slab by slab (left to right) on a second stream while k_hscan2<PHASE 1> follows one slab behind on the
     // map's own stream; the backward phase (PHASE 2), which needs every checkpoint, and everything after it stay as they were.
     // A kernel of this kind lasts as long as ONE of its waves' chains, whatever the number of waves, so splitting by ROWS
     // (or running the vertical scan behind the backward sweep) shortens nothing; only the cost kernel, whose work is not a
     // chain, can hide behind a chain kernel.
-    static const int n_slabs = [] { const char *e = getenv("R3D_SGM_OVERLAP"); const int v = e ? atoi(e) : 4; return v < 2 ? 0 : (v > R3D_SGM_SLABS ? R3D_SGM_SLABS : v); }();
+    // MEASURED (round 2, profiles/r02_overlap_trace.txt, interleaved A/B on one box): the two kernels do run concurrently, but
+    // each then takes 1.5-3x its time alone (cost slab 176 -> 200-310 us, forward slab 120-140 -> 175-455 us), whether the
+    // forward launches own their SIMD (k_hscan2<PHASE 1>, 280 registers) or share it (k_hscan_fwd, 97 registers) and whatever
+    // the chain wave's issue priority: a write stream and a latency-bound read chain interleaved in HBM cost each other more
+    // than running back to back.  320-334 maps/s sequential vs 305-331 overlapped, so the sequential order stays the default.
+    static const int n_slabs = [] { const char *e = getenv("R3D_SGM_OVERLAP"); const int v = e ? atoi(e) : 0; return v < 2 ? 0 : (v > R3D_SGM_SLABS ? R3D_SGM_SLABS : v); }();
     static const bool rows2_env = [] { const char *e = getenv("R3D_HSCAN_ROWS"); return e && !strcmp(e, "2"); }();
     constexpr int KOV = 16;
     // R3D_SGM_FWD=wide: the forward launches use k_hscan2<PHASE 1> (whole register file: cannot share a SIMD with cost waves)

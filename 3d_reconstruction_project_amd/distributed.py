@@ -79,7 +79,8 @@ def _all_gather_fixed(t):
     """All ranks pass a tensor of the SAME shape; returns a [world, *shape] tensor on the same device."""
     import torch
     d = _dist()
-    if d is None or d.get_world_size() == 1:
+    # a one-rank group normally needs no collective; R3D_FORCE_DIST issues it anyway (rehearsal of the RCCL path on one GPU)
+    if d is None or (d.get_world_size() == 1 and not os.environ.get("R3D_FORCE_DIST")):
         return t.unsqueeze(0)
     world = d.get_world_size()
     out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)

@@ -210,7 +210,8 @@ def bench_c5(r3d, ctx, rank, world, n_views=8, reps=3):
                    "register_ms": round(float(st[2]), 3), "fuse_ms": round(float(st[3]), 3), "batch_ms": round(float(st[4]), 3),
                    "views_per_s": round(1e3 * n_views / float(st[4]), 2), "fused_points": int(fused.shape[1]),
                    "fused_checksum": [float(x) for x in chk.cpu().numpy()], "checksum_equal_on_all_ranks": bool(same),
-                   "pose_error_max_abs": terr, "collective": ("rccl all_gather_into_tensor on device tensors" if use_dist else "single rank: no collective issued"),
+                   "pose_error_max_abs": terr, "collective": ("rccl all_gather_into_tensor on device tensors" if use_dist and (world > 1 or os.environ.get("R3D_FORCE_DIST"))
+                                  else "single rank: no collective issued"),
                    "stage_times": "max over ranks of the best of %d repetitions; batch_ms is wall time between barriers" % reps}
             if rank == 0:                            # hand-off to the mesher's input (outside batch_ms)
                 t0 = time.perf_counter()
