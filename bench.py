@@ -59,13 +59,25 @@ def bench_gicp(r3d, ctx, n=1_000_000, iters=20, cpu=True):
     per_iter_ms = res["loop_ms"] / (iters + 1)               # iters+1 evaluate launches, iters solves
     err = float(np.linalg.norm(res["T"] - T_star))
     alg = 88e6
+    traffic = traffic_src = None
+    tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tp):                                   # last committed counter pass (tools/gpu_profile_round.sh), per launch
+        with open(tp) as f:
+            t = json.load(f).get("k_icp_eval")
+        if t and "FETCH_SIZE" in t and "WRITE_SIZE" in t:
+            traffic = round((2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024 / 1e9, 4)
+            traffic_src = "profiles/traffic_latest.json (median of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over k_icp_eval, file dated %s)" % time.strftime(
+                "%Y-%m-%d", time.gmtime(os.path.getmtime(tp)))
+    if err > 1e-3:                                           # SURVEY 8d pass rule for C3
+        raise SystemExit(f"GICP bench: ||T - T*||_F = {err:.3e} > 1e-3")
     out = {"metric": "GICP iterations/s @1M pts", "value": round(1e3 / per_iter_ms, 2), "unit": "iterations/s",
            "iterations": res["iterations"], "ms_per_iteration": round(per_iter_ms, 4),
            "setup_ms": {"normals_knn20_both_clouds": round(1e3 * normals_s, 1), "normals_knn20_both_clouds_first_call": round(1e3 * normals_cold_s, 1),
                         "grid_sort_upload": round(res["setup_ms"], 1)},
            "fitness": round(res["fitness"], 5), "inlier_rmse": res["inlier_rmse"], "T_error_frobenius": err,
            "roofline": {"bound": "hbm", "achieved": round(alg / (per_iter_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK / 1e9,
-                        "unit": "GB/s", "frac": round(alg / (per_iter_ms * 1e-3) / HBM_PEAK, 5), "traffic": None}}
+                        "unit": "GB/s", "frac": round(alg / (per_iter_ms * 1e-3) / HBM_PEAK, 5), "traffic": traffic,
+                        "traffic_unit": "GB/launch (k_icp_eval)", "traffic_source": traffic_src}}
     if cpu:
         from oracle import cloud_oracle as oc               # checker timed as the CPU baseline ("port")
         k = 2
@@ -74,9 +86,10 @@ def bench_gicp(r3d, ctx, n=1_000_000, iters=20, cpu=True):
                         target_normals=tn, target_cov=oc.covariances_from_normals(tn),
                         source_cov=oc.covariances_from_normals(sn))
         dt = time.perf_counter() - tc
-        out["cpu_baseline"] = {"value": round((k + 1) / dt, 3), "unit": "iterations/s", "cores": 1, "kind": "port",
-                               "sample": f"{k} iterations ({k + 1} evaluations) at 1M points, numpy/scipy cKDTree restatement "
-                                         "of Open3D registration_generalized_icp (oracle/cloud_oracle.py)"}
+        out["cpu_baseline"] = {"value": round((k + 1) / dt, 3), "unit": "iterations/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": f"{k} iterations ({k + 1} evaluations) at 1M points, numpy/scipy restatement of Open3D "
+                                         "registration_generalized_icp (oracle/cloud_oracle.py): neighbour search with "
+                                         f"cKDTree.query(workers=-1) on all {os.cpu_count()} host cpus, per-pair 3x3 algebra in numpy (one thread)"}
     return out
 
 
