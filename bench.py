@@ -264,6 +264,12 @@ def main():
                          "r3d_sgbm_compute_batch_dev and overlap on the library's internal lanes (+14 %% maps/s on C2)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON, rank 0): libraries that print banners to file descriptor 1 (RCCL announces its
+    # version there when the group comes up) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -398,7 +404,11 @@ def main():
                                  "slab on a second stream, bracket cost+hscan_fwd) + backward phase (one k_hscan2<PHASE 2> launch, bracket "
                                  "hscan_bwd); the volume is still written once and read three times per map (C twice by hscan, C + sum by "
                                  "vscan): the 40 %% pipeline target stays NOT MET until it is touched twice instead of six times"
-                                 if overlapped else None),
+                                 if overlapped else
+                                 "one map in flight, kernels back to back; by the counters the volume is written twice and read four times per "
+                                 "map (cost writes C; hscan reads C twice and writes the sum; vscan reads C and the sum: 12.9 GB against "
+                                 "B_sgm = 4.06 GB): the 40 % pipeline target is NOT MET, DESIGN.md section 7 has the traces that rule out "
+                                 "overlapping these chain kernels inside one map"),
                         "pipeline_frac": round(ALG_BYTES["map"] * (args.steps / (dev_ms * 1e-3)) / HBM_PEAK, 4)}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
@@ -471,7 +481,8 @@ def main():
                "ms_per_step_repeats": ({"n": len(rep_ms), "min": round(min(rep_ms), 4), "median": round(sorted(rep_ms)[len(rep_ms) // 2], 4),
                                         "max": round(max(rep_ms), 4)} if rep_ms else None),
                "roofline": roofline, "cpu_baseline": cpu, "pipelined": piped, "frame_loop": frame_loop, "secondary": gicp, "c5": c5}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -19,9 +19,20 @@ for i in range(1, 8):
 out["pairwise"] = {"ms": round(1e3 * float(np.median([t[0] for t in ts])), 2), "iterations": [t[1] for t in ts],
                    "setup_ms": round(float(np.median([t[2] for t in ts])), 2), "loop_ms": round(float(np.median([t[3] for t in ts])), 2),
                    "points_after_voxel": ts[0][4]}
-for rep in range(2):      # the first pass grows the device arena to the size of the largest model (one-off allocations)
+feed = [r3d.PointCloud(f) for f in frames]
+for rep in range(3):      # the first pass grows the device arena to the size of the largest model (one-off allocations)
+    log = []
     t0 = time.perf_counter()
-    model = r3d.pipeline.fuse([r3d.PointCloud(f) for f in frames], flavour="icp")
+    model = r3d.pipeline.fuse(feed, flavour="icp", log=log)
     out["fuse_8_frames_ms" if rep else "fuse_8_frames_first_pass_ms"] = round(1e3 * (time.perf_counter() - t0), 1)
 out["model_points"] = len(model.points)
+out["per_frame"] = {"setup_ms": [round(r["setup_ms"], 2) for r in log], "loop_ms": [round(r["loop_ms"], 2) for r in log],
+                    "iterations": [r["iterations"] for r in log]}
+out["sum_setup_ms"] = round(sum(r["setup_ms"] for r in log), 2)
+out["sum_loop_ms"] = round(sum(r["loop_ms"] for r in log), 2)
+# pieces outside the registration calls: first-frame upload and the final download
+m = r3d.cloud_ops.ResidentModel()
+t0 = time.perf_counter(); m.append(frames[0]); r3d.default_context().sync(); out["first_frame_append_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
+m.close()
+t0 = time.perf_counter(); r3d.pipeline.fuse(feed, flavour="icp", resident=False); out["fuse_8_frames_host_model_ms"] = round(1e3 * (time.perf_counter() - t0), 1)
 print(json.dumps(out))
