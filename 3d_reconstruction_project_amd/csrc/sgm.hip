@@ -833,7 +833,10 @@ __global__ void __launch_bounds__(64) k_vscan(const int *__restrict__ cvol, cons
 template <int NPL, int LPC, int K, bool PADDED, int PHASE = 3>
 __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int *__restrict__ hvol, int *__restrict__ ckpt, SgmGeom g,
                                                int seg0, int seg1) {
-    constexpr int DPW = NPL * LPC, RPW = 64 / LPC, CKW = (NPL + 1) * 64;   // words per column, rows per wave
+    // words per column, rows per wave; CKS: words of one checkpoint = the DP/2 packed words of L + its minimum, padded to 16 B.
+    // Checkpoints are addressed by IMAGE ROW, not by wave and lane, so that the two phases may use different lane mappings
+    // (R3D_HSCAN_SPLIT: forward sweep with 2 rows per wave, backward sweep with 4)
+    constexpr int DPW = NPL * LPC, RPW = 64 / LPC, CKS = DPW + 4;
     const int lane = threadIdx.x, k = lane % LPC;
     const int yraw = blockIdx.x * RPW + lane / LPC;
     const bool row_ok = yraw < g.H;
@@ -841,7 +844,7 @@ __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int
     const int *crow = cvol + (size_t)y * g.W1 * DPW + k * NPL;
     int *hrow = hvol + (size_t)y * g.W1 * DPW + k * NPL;
     const int W1 = g.W1, nfull = W1 / K, P1pk = pk_dup(g.P1), P2pk = pk_dup(g.P2);
-    int *ck = ckpt + (size_t)blockIdx.x * (nfull + 1) * CKW + lane * (NPL + 1);
+    int *ckrow = ckpt + (size_t)yraw * (nfull + 1) * CKS, *ck = ckrow + k * NPL;
     const bool valid = 2 * NPL * k < g.D, first = k == 0, last = k == LPC - 1;
     int P[NPL], minp = 0;
     // four rotating cost buffers: a segment is requested two rounds (2*K steps) before its first use and is never
@@ -861,13 +864,13 @@ __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int
     };
     auto save_ck = [&](int sidx) {
 #pragma unroll
-        for (int j = 0; j < NPL; j++) ck[(size_t)sidx * CKW + j] = P[j];
-        ck[(size_t)sidx * CKW + NPL] = minp;
+        for (int j = 0; j < NPL; j++) ck[(size_t)sidx * CKS + j] = P[j];
+        if (first) ckrow[(size_t)sidx * CKS + DPW] = minp;
     };
     auto load_ck = [&](int sidx) {
 #pragma unroll
-        for (int j = 0; j < NPL; j++) P[j] = ck[(size_t)sidx * CKW + j];
-        minp = ck[(size_t)sidx * CKW + NPL];
+        for (int j = 0; j < NPL; j++) P[j] = ck[(size_t)sidx * CKS + j];
+        minp = ckrow[(size_t)sidx * CKS + DPW];
     };
     auto store_sum = [&](int *dst, const int (&a)[NPL], const int (&b)[NPL]) {
         if (row_ok) {
@@ -984,7 +987,7 @@ k_hscan_fwd(const int *__restrict__ cvol, int *__restrict__ hvol, int *__restric
     static_assert(KCK % K == 0, "checkpoint interval is a whole number of buffer segments");
     // (Raising this wave's issue priority with s_setprio 3 was tried: the cost slabs then took 313 us instead of 200-295 and
     // the forward slabs stayed at 200-430 us: the slowdown is in the memory system, not in the issue arbiter.)
-    constexpr int DPW = NPL * LPC, RPW = 64 / LPC, CKW = (NPL + 1) * 64, RATIO = KCK / K;
+    constexpr int DPW = NPL * LPC, RPW = 64 / LPC, CKS = DPW + 4, RATIO = KCK / K;   // checkpoint layout: see k_hscan2
     const int lane = threadIdx.x, k = lane % LPC;
     const int yraw = blockIdx.x * RPW + lane / LPC;
     const bool row_ok = yraw < g.H;
@@ -992,15 +995,15 @@ k_hscan_fwd(const int *__restrict__ cvol, int *__restrict__ hvol, int *__restric
     const int *crow = cvol + (size_t)y * g.W1 * DPW + k * NPL;
     int *hrow = hvol + (size_t)y * g.W1 * DPW + k * NPL;
     const int W1 = g.W1, nck = W1 / KCK, P1pk = pk_dup(g.P1);
-    int *ck = ckpt + (size_t)blockIdx.x * (nck + 1) * CKW + lane * (NPL + 1);
+    int *ckrow = ckpt + (size_t)yraw * (nck + 1) * CKS, *ck = ckrow + k * NPL;
     const bool valid = 2 * NPL * k < g.D, first = k == 0, last = k == LPC - 1;
     const int ck_lo = max(seg0, 0), ck_hi = min(seg1, nck);
     const int sb = ck_lo * RATIO, se = ck_hi * RATIO;          // sub-segments of K columns
     int P[NPL], minp = 0;
     if (ck_lo > 0) {
 #pragma unroll
-        for (int j = 0; j < NPL; j++) P[j] = ck[(size_t)ck_lo * CKW + j];
-        minp = ck[(size_t)ck_lo * CKW + NPL];
+        for (int j = 0; j < NPL; j++) P[j] = ck[(size_t)ck_lo * CKS + j];
+        minp = ckrow[(size_t)ck_lo * CKS + DPW];
     } else {
 #pragma unroll
         for (int j = 0; j < NPL; j++) P[j] = valid ? 0 : PADPK;
@@ -1018,8 +1021,8 @@ k_hscan_fwd(const int *__restrict__ cvol, int *__restrict__ hvol, int *__restric
         load_seg(pre, sidx + 3);
         if (sidx % RATIO == 0) {
 #pragma unroll
-            for (int j = 0; j < NPL; j++) ck[(size_t)(sidx / RATIO) * CKW + j] = P[j];
-            ck[(size_t)(sidx / RATIO) * CKW + NPL] = minp;
+            for (int j = 0; j < NPL; j++) ck[(size_t)(sidx / RATIO) * CKS + j] = P[j];
+            if (first) ckrow[(size_t)(sidx / RATIO) * CKS + DPW] = minp;
         }
 #pragma unroll
         for (int u = 0; u < K; u++) sgm_step_g<NPL, LPC, PADDED>(P, minp, cur[u], P1pk, g.P2, first, last, valid);
@@ -1036,8 +1039,8 @@ k_hscan_fwd(const int *__restrict__ cvol, int *__restrict__ hvol, int *__restric
     }
     if (ck_hi < nck) {                                          // state entering the next launch's first interval
 #pragma unroll
-        for (int j = 0; j < NPL; j++) ck[(size_t)ck_hi * CKW + j] = P[j];
-        ck[(size_t)ck_hi * CKW + NPL] = minp;
+        for (int j = 0; j < NPL; j++) ck[(size_t)ck_hi * CKS + j] = P[j];
+        if (first) ckrow[(size_t)ck_hi * CKS + DPW] = minp;
         return;
     }
     for (int x = nck * KCK; x < W1; x++) {                      // tail columns: forward values parked in the output row
@@ -1998,7 +2001,7 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
             for (int j = 0; j <= R3D_SGM_SLABS; j++) R3D_HIP(ctx, hipEventCreateWithFlags(&ws.slab_ev[j], hipEventDisableTiming));
         const int nfull = g.W1 / KOV, nwaves = (h + 3) / 4;
         const bool padded = g.D != g.DP;
-        if ((rc = r3d_reserve(ctx, ws.ckpt, (size_t)nwaves * (nfull + 1) * (4 + 1) * 64 * 4))) return rc;
+        if ((rc = r3d_reserve(ctx, ws.ckpt, (size_t)(h + 8) * (nfull + 1) * (NPW + 4) * 4))) return rc;
         const int *cp = (const int *)ws.cost.p;
         int *hp = (int *)ws.hsum.p, *kp = (int *)ws.ckpt.p;
         r3d_prof_mark(ctx, ws, st, "cost+hscan_fwd");
@@ -2053,9 +2056,24 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
         const int rpw = four ? 4 : 2, npl = g.DP == 32 ? 1 : g.DP == 64 ? 2 : four ? 4 : 2 * g.NP;
         const int K = g.DP == 32 ? K32 : g.DP == 64 ? K64 : four ? K1b : (g.NP == 1 ? K1 : K2);
         const int nwaves = (h + rpw - 1) / rpw;
-        if ((rc = r3d_reserve(ctx, ws.ckpt, (size_t)nwaves * (g.W1 / K + 1) * (npl + 1) * 64 * 4))) return rc;
+        if ((rc = r3d_reserve(ctx, ws.ckpt, (size_t)(h + 8) * (g.W1 / K + 1) * (NPW + 4) * 4))) return rc;   // by image row (k_hscan2)
         const int *cp = (const int *)ws.cost.p;
         int *hp = (int *)ws.hsum.p, *kp = (int *)ws.ckpt.p;
+        // R3D_HSCAN_SPLIT=1: the two phases as two launches with different lane mappings: the forward sweep (read-only, bound by
+        // the issue rate of ONE wave per SIMD at 4 rows per wave) with 2 rows per wave = 1224 waves, two per SIMD where they
+        // meet, so that one wave's dependency stalls are the other's issue slots; the backward sweep (bandwidth-bound) as it was
+        static const bool split = [] { const char *e = getenv("R3D_HSCAN_SPLIT"); return e && !strcmp(e, "1"); }();
+        (void)npl;
+        if (split && g.DP == 128 && four && g.W1 / K1b >= 1) {
+            const int nfull = g.W1 / K1b, nw2 = (h + 1) / 2;
+            if (padded) {
+                k_hscan2<2, 32, K1b, true, 1><<<nw2, 64, 0, st>>>(cp, hp, kp, g, 0, nfull);
+                k_hscan2<4, 16, K1b, true, 2><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, nfull);
+            } else {
+                k_hscan2<2, 32, K1b, false, 1><<<nw2, 64, 0, st>>>(cp, hp, kp, g, 0, nfull);
+                k_hscan2<4, 16, K1b, false, 2><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, nfull);
+            }
+        } else
         if (g.DP == 32) {
             if (padded) k_hscan2<1, 16, K32, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, 0);
             else k_hscan2<1, 16, K32, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, 0);
