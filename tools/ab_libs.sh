@@ -11,6 +11,6 @@ trap 'cp /tmp/libr3d_keep.so "$L"' EXIT
 for rep in $(seq "$REPS"); do
   for v in A B; do
     if [ $v = A ]; then cp "$A" "$L"; else cp "$B" "$L"; fi
-    python bench.py --no-cpu-baseline --no-gicp 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['value'], d['roofline']['kernel_ms'])"
+    python bench.py --no-cpu-baseline --no-gicp --no-c5 --repeats 2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['value'], d['roofline']['kernel_ms'])"
   done
 done
