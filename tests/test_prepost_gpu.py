@@ -205,3 +205,50 @@ def test_depth2_frame_loop_end_to_end(r3d, synth):
     diff = np.abs(filt.astype(int) - ofilt.astype(int))
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
     np.testing.assert_array_equal(vis, np.uint8(po.normalize_minmax(filt)))
+
+
+def test_config_c1_depth1_chain_640x480(r3d, synth):
+    """BASELINE config C1: one 640x480 pair through the depth1.py chain with the matcher that script builds
+    (initialize_stereo_matcher_sgbm defaults, depth1.py:185-222: numDisparities 16, blockSize 5, P1 = 8*3*25, P2 = 32*3*25,
+    3-way mode, createRightMatcher, WLS lambda 8000 / sigma 1.5) and the rectification of jetson_stereo_8MP_stereo.npz:
+    initUndistortRectifyMap -> remap -> cvtColor -> left / right matcher -> WLS -> the int16 map depth1.py:331-337 displays."""
+    from oracle import sgbm_oracle as so
+    po = _po()
+    c = _calib()
+    W, H, D, bs = 640, 480, 16, 5
+    fl, fr = _color_pair(synth, W, H, D, 41)
+    s = W / 960.0                                             # the file was calibrated at 960x540: scale the pinhole parameters
+    def scaled(K):
+        K = np.array(K, dtype=np.float64)
+        K[:2] *= s
+        return K
+    maps = [r3d.initUndistortRectifyMap(scaled(c["mtx" + k]), c["dist" + k], c["R" + k], scaled(c["P" + k]), (W, H), r3d.CV_16SC2) for k in "12"]
+    for k, (m1, m2) in zip("12", maps):
+        w1, w2 = po.init_undistort_rectify_map(scaled(c["mtx" + k]), c["dist" + k], c["R" + k], scaled(c["P" + k]), (W, H))
+        np.testing.assert_array_equal(m1, w1)
+        np.testing.assert_array_equal(m2, w2)
+    gl = r3d.cvtColor(r3d.remap(fl, *maps[0], r3d.INTER_LINEAR), r3d.COLOR_BGR2GRAY)
+    gr = r3d.cvtColor(r3d.remap(fr, *maps[1], r3d.INTER_LINEAR), r3d.COLOR_BGR2GRAY)
+    ogl, ogr = po.bgr2gray(po.remap_fixed(fl, *maps[0])), po.bgr2gray(po.remap_fixed(fr, *maps[1]))
+    np.testing.assert_array_equal(gl, ogl)
+    np.testing.assert_array_equal(gr, ogr)
+    kw = dict(minDisparity=0, blockSize=bs, P1=8 * 3 * bs ** 2, P2=32 * 3 * bs ** 2, disp12MaxDiff=1, uniquenessRatio=15,
+              speckleWindowSize=0, speckleRange=2, preFilterCap=63)
+    left = r3d.StereoSGBM_create(numDisparities=D, mode=r3d.STEREO_SGBM_MODE_SGBM_3WAY, **kw)
+    plain = left.compute(gl, gr)                              # the matcher as depth1.py:202-214 creates it, before the WLS filter re-configures it
+    np.testing.assert_array_equal(plain, so.compute(ogl, ogr, so.make_params(numDisparities=D, **kw), nthreads=4))
+    right = r3d.createRightMatcher(left)
+    wls = r3d.createDisparityWLSFilter(matcher_left=left)
+    wls.setLambda(8000)
+    wls.setSigmaColor(1.5)
+    dl, dr = left.compute(gl, gr), right.compute(gr, gl)
+    kwl = dict(kw, disp12MaxDiff=1000000, uniquenessRatio=0)
+    odl = so.compute(ogl, ogr, so.make_params(numDisparities=D, **kwl), nthreads=4)
+    odr = so.compute(ogr, ogl, so.make_params(numDisparities=D, **dict(kwl, minDisparity=-D + 1)), nthreads=4)
+    np.testing.assert_array_equal(dl, odl)
+    np.testing.assert_array_equal(dr, odr)
+    filt = wls.filter(dl, gl, None, dr)
+    diff = np.abs(filt.astype(int) - po.wls_filter(odl, ogl, odr, 0, D, bs, lam=8000, sigma_color=1.5).astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+    wls.solver = r3d.stereo_prepost.SOLVER_SEQUENTIAL
+    np.testing.assert_array_equal(wls.filter(dl, gl, None, dr), po.wls_filter(odl, ogl, odr, 0, D, bs, lam=8000, sigma_color=1.5))
