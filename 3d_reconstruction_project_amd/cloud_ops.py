@@ -43,7 +43,49 @@ _lib.register({
 
 
 _i64p = ctypes.POINTER(ctypes.c_int64)
+
+
+class DepthCamera(ctypes.Structure):
+    """r3d_depth_camera: pinhole intrinsics (camera_intrinsic.json) + the depth conversion of create_from_rgbd_image."""
+    _fields_ = [("fx", ctypes.c_double), ("fy", ctypes.c_double), ("ppx", ctypes.c_double), ("ppy", ctypes.c_double),
+                ("depth_scale", ctypes.c_double), ("depth_trunc", ctypes.c_double), ("flip_yz", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+# test/check84.py:158 passes depth_scale = 1.0 / sensor depth scale, the sensor value being the float32 0.001
+DEPTH_SCALE_REALSENSE = float(np.float32(1.0) / np.float32(0.001))
+
+
+def depth_camera(intrinsics, depth_scale=DEPTH_SCALE_REALSENSE, depth_trunc=3.0, flip=True):
+    """intrinsics: dict with fx / fy / ppx / ppy (the reference's camera_intrinsic.json) or a 3x3 matrix."""
+    if isinstance(intrinsics, dict):
+        fx, fy, ppx, ppy = (float(intrinsics[k]) for k in ("fx", "fy", "ppx", "ppy"))
+    else:
+        K = np.asarray(intrinsics, dtype=np.float64).reshape(3, 3)
+        fx, fy, ppx, ppy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    return DepthCamera(fx, fy, ppx, ppy, float(depth_scale), float(depth_trunc), int(bool(flip)), 0)
+
+
+def _depth_args(depth, color):
+    d = np.ascontiguousarray(depth, dtype=np.uint16)
+    if d.ndim != 2:
+        raise ValueError("depth image must be 2-D uint16")
+    c = None
+    if color is not None:
+        c = np.ascontiguousarray(color, dtype=np.uint8)
+        if c.shape != d.shape + (3,):
+            raise ValueError(f"colour image {c.shape} does not match the depth image {d.shape} (3 channels expected)")
+    return d, c
+
+
 _lib.register({
+    "r3d_backproject_depth": ([_vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(DepthCamera), _vp, ctypes.c_int32,
+                               _vp, _vp, _vp, _i64p], ctypes.c_int),
+    "r3d_model_append_depth": ([_vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(DepthCamera), _vp, ctypes.c_int32,
+                                _i64p], ctypes.c_int),
+    "r3d_model_align_append_depth": ([_vp, ctypes.POINTER(AlignParams), _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                      ctypes.POINTER(DepthCamera), _vp, ctypes.c_int32, _vp, ctypes.POINTER(_lib.IcpStats), _i64p, _i64p],
+                                     ctypes.c_int),
     "r3d_model_create": ([_vp, ctypes.POINTER(_vp)], ctypes.c_int),
     "r3d_model_destroy": ([_vp], None),
     "r3d_model_clear": ([_vp], ctypes.c_int),
@@ -312,6 +354,31 @@ class ResidentModel:
         self._call("r3d_model_register_append", ctypes.byref(prm), _ptr(s), _ptr(sc), _ptr(sn), len(s), _ptr(T), ctypes.byref(st))
         return _stats_dict(T, st)
 
+    def append_depth(self, depth, camera, color=None):
+        """First frame given as a depth image (uint16 [H,W]; color uint8 [H,W,3] optional): back-projected on the device."""
+        d, c = _depth_args(depth, color)
+        m = ctypes.c_int64()
+        self._call("r3d_model_append_depth", d.ctypes.data_as(_vp), d.shape[1], d.shape[0], d.shape[1], ctypes.byref(camera),
+                   c.ctypes.data_as(_vp) if c is not None else None, 3 * d.shape[1] if c is not None else 0, ctypes.byref(m))
+        return m.value
+
+    def align_append_depth(self, depth, camera, color=None, threshold=0.02, voxel_size=0.01, max_iteration=100, mode=P2P,
+                           normal_radius=None, normal_max_nn=30, relative_fitness=1e-6, relative_rmse=1e-6, gicp_epsilon=1e-3):
+        """main.py:48-49 for a frame that is still a depth image: create_from_rgbd_image + flip on the device, then align_append."""
+        d, c = _depth_args(depth, color)
+        prm = AlignParams(_lib.IcpParams(int(mode), int(max_iteration), float(threshold), float(relative_fitness),
+                                         float(relative_rmse), float(gicp_epsilon)),
+                          float(voxel_size) if voxel_size else -1.0,
+                          float(normal_radius) if normal_radius else (2.0 * voxel_size if voxel_size else -1.0),
+                          int(normal_max_nn) if normal_max_nn else 0, 0)
+        T = np.empty((4, 4))
+        st = _lib.IcpStats()
+        npts, m = ctypes.c_int64(), ctypes.c_int64()
+        self._call("r3d_model_align_append_depth", ctypes.byref(prm), d.ctypes.data_as(_vp), d.shape[1], d.shape[0], d.shape[1],
+                   ctypes.byref(camera), c.ctypes.data_as(_vp) if c is not None else None, 3 * d.shape[1] if c is not None else 0,
+                   _ptr(T), ctypes.byref(st), ctypes.byref(npts), ctypes.byref(m))
+        return dict(_stats_dict(T, st), frame_points=npts.value, appended=m.value)
+
     def estimate_normals(self, radius=0.05, max_nn=30):
         self._call("r3d_model_estimate_normals", float(radius) if radius else -1.0, int(max_nn))
 
@@ -359,3 +426,20 @@ def transform_points_device(d_points, n, T, d_out, rotate_only=False, ctx=None):
     ctx = ctx or _lib.default_context()
     T = np.ascontiguousarray(T, dtype=np.float64).reshape(4, 4)
     ctx.call("r3d_transform_points_dev", _vp(d_points), int(n), _ptr(T), int(bool(rotate_only)), _vp(d_out))
+
+
+def backproject_depth(depth, camera, color=None, want_pixels=False, ctx=None):
+    """create_from_rgbd_image(+ flip) of test/check84.py:155-159,172-178 (r3d_backproject_depth).  depth: uint16 [H,W];
+    camera: depth_camera(...); color: uint8 [H,W,3] or None.  Returns (points [M,3], colors [M,3] or None[, pixel index [M]])."""
+    ctx = ctx or _lib.default_context()
+    d, c = _depth_args(depth, color)
+    H, W = d.shape
+    pts = np.empty((H * W, 3))
+    col = np.empty((H * W, 3)) if c is not None else None
+    pix = np.empty(H * W, np.int32) if want_pixels else None
+    m = ctypes.c_int64()
+    ctx.call("r3d_backproject_depth", d.ctypes.data_as(_vp), W, H, W, ctypes.byref(camera), c.ctypes.data_as(_vp) if c is not None else None,
+             3 * W if c is not None else 0, _ptr(pts), _ptr(col), pix.ctypes.data_as(_vp) if want_pixels else None, ctypes.byref(m))
+    n = m.value
+    out = (pts[:n].copy(), col[:n].copy() if col is not None else None)
+    return out + (pix[:n].copy(),) if want_pixels else out

@@ -1206,6 +1206,41 @@ __global__ void __launch_bounds__(256) k_reproject(const int16_t *__restrict__ d
     if (pix) pix[o] = (int)i;
 }
 
+// ------------------------------------------------------------------------------------------------ depth image -> cloud
+// open3d.geometry.PointCloud.create_from_rgbd_image(RGBDImage.create_from_color_and_depth(color, depth, depth_scale, depth_trunc,
+// convert_rgb_to_intensity=False), intrinsic) followed by the flip of test/check84.py:155-159,172-178 -- the rule SURVEY.md
+// Appendix C verified on all 163 recorded frames: z = float(raw) / float(depth_scale) in FLOAT32, z > depth_trunc or z == 0
+// dropped, x = (u - ppx) z / fx, y = (v - ppy) z / fy in float64 (u = column, v = row), then (x, -y, -z); row-major pixel order;
+// colours = channel / 255.
+struct DepthCam { double fx, fy, ppx, ppy; float scale, trunc; int flip; };
+__device__ __forceinline__ float depth_z(unsigned short raw, const DepthCam &c) {
+    const float z = (float)raw / c.scale;
+    return z > c.trunc ? 0.0f : z;
+}
+__global__ void __launch_bounds__(256) k_depth_flags(const unsigned short *__restrict__ depth, int w, int stride, int64_t n, DepthCam c,
+                                                     int *__restrict__ flags) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    flags[i] = depth_z(depth[(i / w) * stride + (i % w)], c) > 0.0f ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_backproject(const unsigned short *__restrict__ depth, const unsigned char *__restrict__ color,
+                                                     const int *__restrict__ flags, const int *__restrict__ scan, int w, int stride,
+                                                     int cstride, int64_t n, DepthCam c, double *__restrict__ xyz, double *__restrict__ rgb,
+                                                     int *__restrict__ pix) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    const int u = (int)(i % w), v = (int)(i / w);
+    const double z = (double)depth_z(depth[(int64_t)v * stride + u], c);
+    const double x = ((double)u - c.ppx) * z / c.fx, y = ((double)v - c.ppy) * z / c.fy;
+    const int64_t o = scan[i];
+    xyz[o * 3] = x; xyz[o * 3 + 1] = c.flip ? -y : y; xyz[o * 3 + 2] = c.flip ? -z : z;
+    if (rgb) {
+        const unsigned char *p = color + (int64_t)v * cstride + 3 * u;
+        rgb[o * 3] = (double)p[0] / 255.0; rgb[o * 3 + 1] = (double)p[1] / 255.0; rgb[o * 3 + 2] = (double)p[2] / 255.0;
+    }
+    if (pix) pix[o] = (int)i;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 struct DevArena {  // simple bump allocator over ctx->cloud_bufs (grow-only, reused across calls)
     r3d_ctx *ctx;
@@ -1567,6 +1602,53 @@ int reproject_core(r3d_ctx *ctx, DevArena &ar, const int16_t *d_d, int w, int h,
     R3D_HIP(ctx, hipGetLastError());
     *d_xyz_out = d_xyz;
     if (d_pix_out) *d_pix_out = d_pix;
+    return R3D_OK;
+}
+
+// depth image (host) -> compacted xyz / colours (device); everything below r3d_backproject_depth's argument checks
+int backproject_core(r3d_ctx *ctx, DevArena &ar, const uint16_t *depth, int w, int h, int stride, const r3d_depth_camera *cam,
+                     const uint8_t *color, int cstride, bool want_pix, double **d_xyz_out, double **d_rgb_out, int **d_pix_out, int64_t *m_out) {
+    const int64_t n = (int64_t)w * h;
+    if (n > 0x7fffffff) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "backproject_depth: image too large");
+    unsigned short *d_d = (unsigned short *)ar.get((size_t)stride * h * 2);
+    unsigned char *d_c = color ? (unsigned char *)ar.get((size_t)cstride * h) : nullptr;
+    int *flags = (int *)ar.get((size_t)n * 4), *scan = (int *)ar.get((size_t)n * 4);
+    if (ar.rc) return ar.rc;
+    R3D_HIP(ctx, hipMemcpyAsync(d_d, depth, (size_t)stride * h * 2, hipMemcpyHostToDevice, ctx->stream));
+    if (color) R3D_HIP(ctx, hipMemcpyAsync(d_c, color, (size_t)cstride * h, hipMemcpyHostToDevice, ctx->stream));
+    DepthCam c{cam->fx, cam->fy, cam->ppx, cam->ppy, (float)cam->depth_scale, (float)cam->depth_trunc, cam->flip_yz};
+    const int nb = (int)((n + 255) / 256);
+    k_depth_flags<<<nb, 256, 0, ctx->stream>>>(d_d, w, stride, n, c, flags);
+    size_t tb = 0;
+    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flags, scan, (int)n, ctx->stream));
+    void *tmp = ar.get(tb);
+    if (ar.rc) return ar.rc;
+    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tb, flags, scan, (int)n, ctx->stream));
+    int ls = 0, lf = 0;
+    R3D_HIP(ctx, hipMemcpyAsync(&ls, scan + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipMemcpyAsync(&lf, flags + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t m = (int64_t)ls + lf;
+    *m_out = m;
+    *d_xyz_out = nullptr;
+    if (d_rgb_out) *d_rgb_out = nullptr;
+    if (d_pix_out) *d_pix_out = nullptr;
+    if (m == 0) return R3D_OK;
+    double *d_xyz = (double *)ar.get((size_t)m * 24), *d_rgb = color ? (double *)ar.get((size_t)m * 24) : nullptr;
+    int *d_pix = want_pix ? (int *)ar.get((size_t)m * 4) : nullptr;
+    if (ar.rc) return ar.rc;
+    k_backproject<<<nb, 256, 0, ctx->stream>>>(d_d, d_c, flags, scan, w, stride, cstride, n, c, d_xyz, d_rgb, d_pix);
+    R3D_HIP(ctx, hipGetLastError());
+    *d_xyz_out = d_xyz;
+    if (d_rgb_out) *d_rgb_out = d_rgb;
+    if (d_pix_out) *d_pix_out = d_pix;
+    return R3D_OK;
+}
+static int depth_args_ok(r3d_ctx *ctx, const uint16_t *depth, int w, int h, int stride, const r3d_depth_camera *cam, const uint8_t *color,
+                         int cstride, const char *who) {
+    if (!depth || !cam || w <= 0 || h <= 0 || stride < w || (color && cstride < 3 * w)) return r3d_fail(ctx, R3D_E_BADARG, "%s: bad argument", who);
+    if (!(cam->fx != 0) || !(cam->fy != 0) || !(cam->depth_scale > 0) || !(cam->depth_trunc > 0))
+        return r3d_fail(ctx, R3D_E_BADARG, "%s: focal lengths must be non-zero, depth_scale and depth_trunc positive", who);
     return R3D_OK;
 }
 
@@ -2356,25 +2438,25 @@ int r3d_model_append(r3d_model *m, const double *xyz, const double *colors, cons
     return model_append(m, xyz, colors, normals, n, hipMemcpyHostToDevice);
 }
 
-int r3d_model_align_append(r3d_model *m, const r3d_align_params *p, const double *src, const double *src_colors, int64_t ns,
-                           double *T4x4, r3d_icp_stats *stats, int64_t *appended) {
-    R3D_ROCTX_RANGE("r3d_model_align_append");
-    if (!m) return R3D_E_BADARG;
+}  // extern "C"
+namespace {
+int model_align_checks(r3d_model *m, const r3d_align_params *p, const char *who) {
     r3d_ctx *ctx = m->ctx;
-    if (!p || !src || !T4x4 || ns <= 0) return r3d_fail(ctx, R3D_E_BADARG, "model_align_append: bad argument");
-    if (m->n <= 0) return r3d_fail(ctx, R3D_E_BADARG, "model_align_append: the model is empty (append the first frame)");
+    if (m->n <= 0) return r3d_fail(ctx, R3D_E_BADARG, "%s: the model is empty (append the first frame)", who);
     const r3d_icp_params *ip = &p->icp;
-    if (ip->mode < 0 || ip->mode > 2) return r3d_fail(ctx, R3D_E_BADARG, "model_align_append: mode must be 0 (P2P), 1 (P2PLANE) or 2 (GICP)");
-    if (!(ip->max_correspondence_distance > 0)) return r3d_fail(ctx, R3D_E_BADARG, "model_align_append: max_correspondence_distance must be > 0");
-    if (p->normal_max_nn > 128) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "model_align_append: normal_max_nn > 128 not supported");
-    if (ip->mode != MODE_P2P && p->normal_max_nn <= 0) return r3d_fail(ctx, R3D_E_BADARG, "model_align_append: this mode needs normals (normal_max_nn > 0)");
-    R3D_HIP(ctx, hipSetDevice(ctx->device));
-    const auto t_begin = std::chrono::steady_clock::now();
-    DevArena ar(ctx);
+    if (ip->mode < 0 || ip->mode > 2) return r3d_fail(ctx, R3D_E_BADARG, "%s: mode must be 0 (P2P), 1 (P2PLANE) or 2 (GICP)", who);
+    if (!(ip->max_correspondence_distance > 0)) return r3d_fail(ctx, R3D_E_BADARG, "%s: max_correspondence_distance must be > 0", who);
+    if (p->normal_max_nn > 128) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "%s: normal_max_nn > 128 not supported", who);
+    if (ip->mode != MODE_P2P && p->normal_max_nn <= 0) return r3d_fail(ctx, R3D_E_BADARG, "%s: this mode needs normals (normal_max_nn > 0)", who);
+    return R3D_OK;
+}
+// the frame (d_s, optional colours d_c, ns points) is already on the device in arena `ar`
+int model_align_core(r3d_model *m, DevArena &ar, const r3d_align_params *p, double *d_s, double *d_c, int64_t ns, double *T4x4,
+                     r3d_icp_stats *stats, int64_t *appended, std::chrono::steady_clock::time_point t_begin) {
+    r3d_ctx *ctx = m->ctx;
+    const r3d_icp_params *ip = &p->icp;
     int rc;
-    double *d_s, *d_c = nullptr, *d_t = (double *)m->pts.p;
-    if ((rc = upload(ctx, ar, src, ns * 3, &d_s))) return rc;
-    if (src_colors && (rc = upload(ctx, ar, src_colors, ns * 3, &d_c))) return rc;
+    double *d_t = (double *)m->pts.p;
     int64_t ms = ns, mt = m->n;
     if (p->voxel_size > 0) {  // pointcloud_alignment.py:22-23 on the frame and on the WHOLE resident model
         VoxelSegs V;
@@ -2414,6 +2496,93 @@ int r3d_model_align_append(r3d_model *m, const r3d_align_params *p, const double
     R3D_HIP(ctx, hipGetLastError());
     if ((rc = model_append(m, d_o, d_c, d_on, ms, hipMemcpyDeviceToDevice))) return rc;   // main.py:49 combined += aligned
     if (appended) *appended = ms;
+    return R3D_OK;
+}
+}  // namespace
+extern "C" {
+
+int r3d_model_align_append(r3d_model *m, const r3d_align_params *p, const double *src, const double *src_colors, int64_t ns,
+                           double *T4x4, r3d_icp_stats *stats, int64_t *appended) {
+    R3D_ROCTX_RANGE("r3d_model_align_append");
+    if (!m) return R3D_E_BADARG;
+    r3d_ctx *ctx = m->ctx;
+    if (!p || !src || !T4x4 || ns <= 0) return r3d_fail(ctx, R3D_E_BADARG, "model_align_append: bad argument");
+    int rc;
+    if ((rc = model_align_checks(m, p, "model_align_append"))) return rc;
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    const auto t_begin = std::chrono::steady_clock::now();
+    DevArena ar(ctx);
+    double *d_s, *d_c = nullptr;
+    if ((rc = upload(ctx, ar, src, ns * 3, &d_s))) return rc;
+    if (src_colors && (rc = upload(ctx, ar, src_colors, ns * 3, &d_c))) return rc;
+    return model_align_core(m, ar, p, d_s, d_c, ns, T4x4, stats, appended, t_begin);
+}
+
+// The same two steps of main.py:34-49 for a frame that is still a DEPTH IMAGE (the recorded frames of test/output84, a RealSense
+// z16 frame): create_from_rgbd_image + flip (test/check84.py:155-159,172-178) runs on the device, so a 0.6 MB image goes up
+// instead of 6.8 MB of float64 points.  color (may be NULL): uint8 [h][w][3], channels taken in the order given.
+int r3d_model_append_depth(r3d_model *m, const uint16_t *depth, int32_t w, int32_t h, int32_t stride, const r3d_depth_camera *cam,
+                           const uint8_t *color, int32_t color_stride, int64_t *appended) {
+    R3D_ROCTX_RANGE("r3d_model_append_depth");
+    if (!m) return R3D_E_BADARG;
+    r3d_ctx *ctx = m->ctx;
+    int rc;
+    if ((rc = depth_args_ok(ctx, depth, w, h, stride, cam, color, color_stride, "model_append_depth"))) return rc;
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    DevArena ar(ctx);
+    double *d_p, *d_c;
+    int64_t n;
+    if ((rc = backproject_core(ctx, ar, depth, w, h, stride, cam, color, color_stride, false, &d_p, &d_c, nullptr, &n))) return rc;
+    if (appended) *appended = n;
+    if (n == 0) return R3D_OK;
+    return model_append(m, d_p, d_c, nullptr, n, hipMemcpyDeviceToDevice);
+}
+
+int r3d_model_align_append_depth(r3d_model *m, const r3d_align_params *p, const uint16_t *depth, int32_t w, int32_t h, int32_t stride,
+                                 const r3d_depth_camera *cam, const uint8_t *color, int32_t color_stride, double *T4x4, r3d_icp_stats *stats,
+                                 int64_t *frame_points, int64_t *appended) {
+    R3D_ROCTX_RANGE("r3d_model_align_append_depth");
+    if (!m) return R3D_E_BADARG;
+    r3d_ctx *ctx = m->ctx;
+    if (!p || !T4x4) return r3d_fail(ctx, R3D_E_BADARG, "model_align_append_depth: bad argument");
+    int rc;
+    if ((rc = depth_args_ok(ctx, depth, w, h, stride, cam, color, color_stride, "model_align_append_depth"))) return rc;
+    if ((rc = model_align_checks(m, p, "model_align_append_depth"))) return rc;
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    const auto t_begin = std::chrono::steady_clock::now();
+    DevArena ar(ctx);
+    double *d_p, *d_c;
+    int64_t n;
+    if ((rc = backproject_core(ctx, ar, depth, w, h, stride, cam, color, color_stride, false, &d_p, &d_c, nullptr, &n))) return rc;
+    if (frame_points) *frame_points = n;
+    if (appended) *appended = 0;
+    if (n == 0) {   // no valid pixel: a failed capture, skipped like main.py:53-54 (identity, empty statistics, nothing appended)
+        for (int i = 0; i < 16; i++) T4x4[i] = (i % 5 == 0);
+        if (stats) memset(stats, 0, sizeof *stats);
+        return R3D_OK;
+    }
+    return model_align_core(m, ar, p, d_p, d_c, n, T4x4, stats, appended, t_begin);
+}
+
+int r3d_backproject_depth(r3d_ctx *ctx, const uint16_t *depth, int32_t w, int32_t h, int32_t stride, const r3d_depth_camera *cam,
+                          const uint8_t *color, int32_t color_stride, double *out_xyz, double *out_colors, int32_t *out_pixel, int64_t *out_n) {
+    R3D_ROCTX_RANGE("r3d_backproject_depth");
+    if (!ctx) return R3D_E_BADARG;
+    if (!out_xyz || !out_n || (color && !out_colors)) return r3d_fail(ctx, R3D_E_BADARG, "backproject_depth: bad argument");
+    int rc;
+    if ((rc = depth_args_ok(ctx, depth, w, h, stride, cam, color, color_stride, "backproject_depth"))) return rc;
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    DevArena ar(ctx);
+    double *d_p, *d_c;
+    int *d_pix;
+    int64_t n;
+    if ((rc = backproject_core(ctx, ar, depth, w, h, stride, cam, color, color_stride, out_pixel != nullptr, &d_p, &d_c, &d_pix, &n))) return rc;
+    *out_n = n;
+    if (n == 0) return R3D_OK;
+    R3D_HIP(ctx, hipMemcpyAsync(out_xyz, d_p, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    if (d_c) R3D_HIP(ctx, hipMemcpyAsync(out_colors, d_c, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_pixel) R3D_HIP(ctx, hipMemcpyAsync(out_pixel, d_pix, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return R3D_OK;
 }
 

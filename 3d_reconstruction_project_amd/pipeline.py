@@ -65,6 +65,38 @@ def fuse(frames, flavour="icp", verbose=False, resident=True, ctx=None, log=None
     return PointCloud(pts, cols, nrm)
 
 
+def fuse_depth_frames(depth_images, camera, colors=None, verbose=False, ctx=None, log=None, threshold=0.02, voxel_size=0.01, max_iter=100):
+    """main.py:34-54 for frames that arrive as depth images (the recorded test/output84 frames; a RealSense z16 frame):
+    create_from_rgbd_image + flip (test/check84.py:155-159,172-178) runs on the device, the model stays in HBM, the frame that
+    crosses PCIe is the 0.6 MB image.  depth_images: iterable of uint16 [H,W] arrays (None / all-invalid = failed capture,
+    skipped); camera: cloud_ops.depth_camera(intrinsics); colors: optional iterable of uint8 [H,W,3] images.
+    Identical to fuse() over the back-projected clouds."""
+    model = None
+    colors = iter(colors) if colors is not None else None
+    for depth in depth_images:
+        col = next(colors) if colors is not None else None
+        if depth is None or not np.any(depth):
+            if verbose:
+                print("No valid point cloud captured, skipping frame.")      # main.py:53-54
+            continue
+        if model is None:
+            model = cloud_ops.ResidentModel(ctx)
+            if model.append_depth(depth, camera, col) == 0:
+                model.close()
+                model = None
+            continue
+        res = model.align_append_depth(depth, camera, col, threshold, voxel_size, max_iter, cloud_ops.P2P, 2 * voxel_size, 30)
+        if res["frame_points"] == 0:                                          # nothing within depth_trunc: a failed capture
+            continue
+        if log is not None:
+            log.append(res)
+    if model is None:
+        return PointCloud()
+    pts, cols, nrm = model.download()
+    model.close()
+    return PointCloud(pts, cols, nrm)
+
+
 def _fuse_host(frames, flavour, verbose, log, **align_kw):
     model = PointCloud()
     aligner = PointCloudAlignment(verbose=verbose) if flavour == "icp" else GeneralizedICPAlignment()

@@ -242,6 +242,30 @@ int r3d_model_append(r3d_model *m, const double *xyz, const double *colors, cons
  * *appended (may be NULL) = points added (the down-sampled frame). */
 int r3d_model_align_append(r3d_model *m, const r3d_align_params *p, const double *src, const double *src_colors, int64_t ns,
                            double *T4x4, r3d_icp_stats *stats, int64_t *appended);
+/* replaces: o3d.geometry.PointCloud.create_from_rgbd_image(o3d.geometry.RGBDImage.create_from_color_and_depth(color, depth,
+ *           depth_scale, depth_trunc, convert_rgb_to_intensity=False), intrinsic) + the flip transform   test/check84.py:155-159,
+ * 172-178 -- how every recorded frame of test/output84 became a cloud (verified on all 163 frames, so this
+ * entry point is PINNED by the reference's own PLY files).  z = float32(raw) / float32(depth_scale); z > depth_trunc or z == 0
+ * dropped; x = (u - ppx) z / fx, y = (v - ppy) z / fy in float64; flip_yz != 0: (x, -y, -z).  Row-major pixel order.  depth:
+ * uint16 [h][stride]; color (may be NULL): uint8 [h][color_stride bytes] with 3 channels per pixel, written as channel / 255 in
+ * the order given.  Output arrays need room for w*h entries; out_pixel (may be NULL) = linear pixel index of every point. */
+typedef struct r3d_depth_camera {
+    double fx, fy, ppx, ppy;   /* camera_intrinsic.json */
+    double depth_scale;        /* raw units per metre as the script passes it: 1.0 / sensor depth scale (cast to float32 inside) */
+    double depth_trunc;        /* metres; 3.0 in the reference */
+    int32_t flip_yz;           /* 1: the (x, -y, -z) flip of check84.py:172-178 */
+    int32_t reserved;
+} r3d_depth_camera;
+int r3d_backproject_depth(r3d_ctx *ctx, const uint16_t *depth, int32_t w, int32_t h, int32_t stride, const r3d_depth_camera *cam,
+                          const uint8_t *color, int32_t color_stride, double *out_xyz, double *out_colors, int32_t *out_pixel, int64_t *out_n);
+/* the first frame / a later frame of the scanning loop given as a DEPTH IMAGE: back-projection on the device, then exactly
+ * r3d_model_append / r3d_model_align_append (0.6 MB goes up instead of 6.8 MB of float64 points).  *frame_points = valid pixels;
+ * a frame without any (a failed capture, main.py:53-54) changes nothing: identity, zeroed statistics, *appended = 0. */
+int r3d_model_append_depth(r3d_model *m, const uint16_t *depth, int32_t w, int32_t h, int32_t stride, const r3d_depth_camera *cam,
+                           const uint8_t *color, int32_t color_stride, int64_t *appended);
+int r3d_model_align_append_depth(r3d_model *m, const r3d_align_params *p, const uint16_t *depth, int32_t w, int32_t h, int32_t stride,
+                                 const r3d_depth_camera *cam, const uint8_t *color, int32_t color_stride, double *T4x4, r3d_icp_stats *stats,
+                                 int64_t *frame_points, int64_t *appended);
 /* test/GICP1.py:145-146: aligned = align_point_clouds(frame, combined) (registration of the frame against the WHOLE model with
  * its normals, :99-103, from identity); combined += aligned.  src_colors / src_normals may be NULL where the mode allows. */
 int r3d_model_register_append(r3d_model *m, const r3d_icp_params *p, const double *src, const double *src_colors, const double *src_normals,

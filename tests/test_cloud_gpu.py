@@ -526,3 +526,57 @@ def test_c3_gicp_at_one_million_points_matches_oracle(r3d, c3):
         w = co.registration(src, tgt, 0.02, mode=name, max_iteration=1, relative_fitness=-1, relative_rmse=-1, target_normals=tn)
         assert g["correspondences"] == w["correspondences"] and abs(g["inlier_rmse"] - w["inlier_rmse"]) < 1e-9
         assert np.abs(g["T"] - w["T"]).max() < 1e-9
+
+
+# ------------------------------------------------------------------ depth image -> cloud (PINNED by the recorded PLY files)
+@pytest.mark.parametrize("sub,frame", [("output84", 8), ("output84", 11), ("output", 8), ("output", 10)])
+def test_backproject_depth_reproduces_recorded_ply(r3d, sub, frame):
+    """create_from_rgbd_image + flip (test/check84.py:155-159,172-178) on the device: equal to the oracle point for point, and
+    after voxel_down_sample(0.02) (+ the outlier filter of that capture) equal to the PLY the reference itself recorded."""
+    from PIL import Image
+    d = co.read_png16(os.path.join(GOLDEN, f"{sub}/depth_{frame:05d}.png"))
+    cam = r3d.cloud_ops.depth_camera(INTR)
+    pts, col, pix = r3d.cloud_ops.backproject_depth(d, cam, want_pixels=True)
+    want, (v, u) = co.backproject(d, INTR)
+    np.testing.assert_array_equal(pts, want)
+    np.testing.assert_array_equal(pix, v * d.shape[1] + u)
+    assert col is None
+    ply = co.read_ply(os.path.join(GOLDEN, f"{sub}/pcd_{frame:05d}.ply"))
+    vox, _, _ = r3d.cloud_ops.voxel_down_sample(pts, 0.02)
+    if sub == "output":                                        # that capture also ran remove_statistical_outlier(20, 2.0)
+        vox = vox[r3d.cloud_ops.statistical_outlier_mask(vox, 20, 2.0)]
+    a, = _sorted(vox)
+    b, = _sorted(ply["points"])
+    assert a.shape == b.shape and np.abs(a - b).max() == 0.0
+    if sub == "output84" and frame == 8:                       # colours: channel / 255, voxel means as recorded
+        img = np.asarray(Image.open(os.path.join(GOLDEN, "output84/color_00008.png")))
+        p2, c2 = r3d.cloud_ops.backproject_depth(d, cam, color=img)
+        np.testing.assert_array_equal(p2, want)
+        np.testing.assert_array_equal(c2, img[v, u] / 255.0)
+    # options: no flip, other truncation; an image without a valid pixel gives an empty cloud
+    nf, _ = r3d.cloud_ops.backproject_depth(d, r3d.cloud_ops.depth_camera(INTR, depth_trunc=1.5, flip=False))
+    wf, _ = co.backproject(d, INTR, depth_trunc=1.5, flip=False)
+    np.testing.assert_array_equal(nf, wf)
+    assert r3d.cloud_ops.backproject_depth(np.zeros((4, 5), np.uint16), cam)[0].shape == (0, 3)
+
+
+def test_scanning_loop_from_depth_images_equals_loop_over_clouds(r3d):
+    """main.py:34-54 fed with the recorded depth PNGs (back-projection on the device, model in HBM) == the same loop over the
+    oracle's back-projected clouds, colours included; failed captures (None, all-zero, everything beyond depth_trunc) are skipped."""
+    from PIL import Image
+    depths = [co.read_png16(os.path.join(GOLDEN, f"output84/depth_{i:05d}.png")) for i in (8, 9, 10)]
+    img = np.asarray(Image.open(os.path.join(GOLDEN, "output84/color_00008.png")))
+    cam = r3d.cloud_ops.depth_camera(INTR)
+    far = np.full_like(depths[0], 60000)                       # 60 m: beyond depth_trunc
+    feed = [None, depths[0], np.zeros_like(depths[0]), depths[1], far, depths[2]]
+    log = []
+    got = r3d.pipeline.fuse_depth_frames(feed, cam, colors=[img] * len(feed), log=log)
+    clouds = []
+    for d in depths:
+        p, (v, u) = co.backproject(d, INTR)
+        clouds.append(r3d.PointCloud(p, colors=img[v, u] / 255.0))
+    want = r3d.pipeline.fuse(clouds, flavour="icp")
+    assert len(log) == 2 and log[0]["frame_points"] == len(clouds[1])
+    np.testing.assert_array_equal(got.points, want.points)
+    np.testing.assert_array_equal(got.colors, want.colors)
+    assert r3d.pipeline.fuse_depth_frames([None, far], cam).points.shape == (0, 3)

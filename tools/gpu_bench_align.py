@@ -35,4 +35,12 @@ m = r3d.cloud_ops.ResidentModel()
 t0 = time.perf_counter(); m.append(frames[0]); r3d.default_context().sync(); out["first_frame_append_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
 m.close()
 t0 = time.perf_counter(); r3d.pipeline.fuse(feed, flavour="icp", resident=False); out["fuse_8_frames_host_model_ms"] = round(1e3 * (time.perf_counter() - t0), 1)
+depths = [co.read_png16(os.path.join(G, f"output84/depth_{i:05d}.png")) for i in range(8, 16)]
+cam = r3d.cloud_ops.depth_camera(intr)
+r3d.pipeline.fuse_depth_frames(depths, cam)
+ts = []
+for rep in range(3):
+    t0 = time.perf_counter(); md = r3d.pipeline.fuse_depth_frames(depths, cam); ts.append(time.perf_counter() - t0)
+out["fuse_8_depth_images_ms"] = round(1e3 * min(ts), 1)
+out["depth_loop_equals_cloud_loop"] = bool(np.array_equal(md.points, model.points))
 print(json.dumps(out))
