@@ -111,3 +111,53 @@ def test_cloud_oracle_equals_open3d():
     mine_r = oc.registration(src, tgt, 0.02, mode="gicp", max_iteration=30, target_normals=n_ref,
                              target_cov=oc.covariances_from_normals(n_ref), source_cov=oc.covariances_from_normals(sn))
     np.testing.assert_allclose(mine_r["T"], r.transformation, atol=1e-6)
+
+
+def test_round2_oracles_equal_open3d():
+    """Orientation graph (incl. the Delaunay-edges-block-k-NN quirk), tensor voxel grid, statistical outlier rule with coincident
+    points, create_from_rgbd_image: the restatements added in round 2, against Open3D when it is installed."""
+    o3d = pytest.importorskip("open3d")
+    import os
+    from oracle import cloud_oracle as oc
+    from tests.conftest import GOLDEN
+
+    def pc(a, n=None):
+        p = o3d.geometry.PointCloud()
+        p.points = o3d.utility.Vector3dVector(a)
+        if n is not None:
+            p.normals = o3d.utility.Vector3dVector(n)
+        return p
+    rng = np.random.default_rng(0)
+    # orientation: random signs on a noisy sphere; equal weights are rare, so the spanning trees (and with them every sign) agree
+    v = rng.standard_normal((4000, 3))
+    p = 0.5 * v / np.linalg.norm(v, axis=1, keepdims=True) + rng.normal(0, 2e-3, (4000, 3))
+    n = p / np.linalg.norm(p, axis=1, keepdims=True) * np.where(rng.random(len(p)) < 0.5, -1.0, 1.0)[:, None]
+    ref = pc(p, n)
+    ref.orient_normals_consistent_tangent_plane(30)
+    mine = oc.orient_normals(p, n, 30)
+    agree = (np.sign((np.asarray(ref.normals) * mine).sum(1)) > 0).mean()
+    assert agree == 1.0, f"orientation oracle agrees with Open3D on {agree:.4%} of the normals"
+    # tensor voxel grid (float32, origin 0, mean reduction)
+    q = (rng.random((5000, 3)) * 0.3 - 0.1)
+    t = o3d.t.geometry.PointCloud(o3d.core.Tensor(q.astype(np.float32)))
+    ref_v = t.voxel_down_sample(0.01).point.positions.numpy().astype(np.float64)
+    mine_v = oc.voxel_down_sample_tensor(q, 0.01)
+    order = lambda a: a[np.lexsort(a.T[::-1])]                                          # noqa: E731
+    assert ref_v.shape == mine_v.shape
+    np.testing.assert_allclose(order(mine_v), order(ref_v), atol=1e-6)                  # float32 sums in a different order
+    # statistical outlier rule with >= k coincident points
+    dup = np.concatenate([q[:400], np.repeat(q[:5], 6, axis=0)])
+    _, ind = pc(dup).remove_statistical_outlier(nb_neighbors=5, std_ratio=1.0)
+    mask = np.zeros(len(dup), bool)
+    mask[np.asarray(ind)] = True
+    np.testing.assert_array_equal(oc.statistical_outlier_mask(dup, 5, 1.0), mask)
+    # create_from_rgbd_image + flip on a recorded frame
+    depth = oc.read_png16(os.path.join(GOLDEN, "output84/depth_00008.png"))
+    intr = oc.read_intrinsics(os.path.join(GOLDEN, "camera_intrinsic.json"))
+    color = o3d.geometry.Image(np.zeros(depth.shape + (3,), np.uint8))
+    rgbd = o3d.geometry.RGBDImage.create_from_color_and_depth(color, o3d.geometry.Image(depth), depth_scale=float(oc.DEPTH_SCALE_F32),
+                                                              depth_trunc=3.0, convert_rgb_to_intensity=False)
+    cam = o3d.camera.PinholeCameraIntrinsic(depth.shape[1], depth.shape[0], intr["fx"], intr["fy"], intr["ppx"], intr["ppy"])
+    refc = o3d.geometry.PointCloud.create_from_rgbd_image(rgbd, cam)
+    refc.transform([[1, 0, 0, 0], [0, -1, 0, 0], [0, 0, -1, 0], [0, 0, 0, 1]])
+    np.testing.assert_array_equal(oc.backproject(depth, intr)[0], np.asarray(refc.points))
