@@ -297,7 +297,9 @@ def main():
         # stream (the C5 leg switches it to the stream it shares with torch / RCCL)
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        import datetime
+        # a rank that dies inside a collective must not leave the others waiting for the default 10 minutes
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=240))
     L, R, _ = r3d.synth.stereo_pair(W, H, D, seed=20241008 + rank)
     dL, dR = ctx.to_device(L), ctx.to_device(R)
     lanes = max(1, min(args.lanes, 3))
@@ -375,7 +377,12 @@ def main():
     c5 = None
     if not args.no_c5:
         ctx.set_profiling(False)
-        c5 = bench_c5(r3d, ctx, rank, world)
+        try:
+            c5 = bench_c5(r3d, ctx, rank, world)
+        except Exception as e:  # noqa: BLE001  the headline line must still be printed; the failure is reported in its place
+            import traceback
+            traceback.print_exc()
+            c5 = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         value = world * args.steps / elapsed
         # default build: the cost kernel runs slab by slab on a second stream underneath the forward phase of the horizontal scan
