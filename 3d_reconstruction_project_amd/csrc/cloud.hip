@@ -63,9 +63,11 @@ __global__ void __launch_bounds__(256) k_bbox_partial(const double *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ keys
+// KEY = unsigned (the key space fits 32 bits: half the bytes through every radix pass) or unsigned long long
+template <class KEY>
 __global__ void __launch_bounds__(256) k_cell_keys(const double *__restrict__ p, int64_t n, double ox, double oy, double oz,
                                                    double cell, int nx, int ny, int nz, int key_order,
-                                                   unsigned long long *__restrict__ keys, int *__restrict__ vals) {
+                                                   KEY *__restrict__ keys, int *__restrict__ vals) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     int cx, cy, cz;
@@ -98,23 +100,25 @@ __global__ void __launch_bounds__(256) k_cell_keys(const double *__restrict__ p,
     } else {
         k = key_order == 0 ? ((unsigned long long)cz * ny + cy) * nx + cx : ((unsigned long long)cx * ny + cy) * nz + cz;   // 1 and 3: z fastest
     }
-    keys[i] = k;
+    keys[i] = (KEY)k;
     vals[i] = (int)i;
 }
 
 // population of every cell: the last point of a run of equal (sorted) keys knows the run length
-__global__ void __launch_bounds__(256) k_cell_counts(const unsigned long long *__restrict__ keys, int64_t n, int *__restrict__ run_start,
+template <class KEY>
+__global__ void __launch_bounds__(256) k_cell_counts(const KEY *__restrict__ keys, int64_t n, int *__restrict__ run_start,
                                                      int *__restrict__ counts) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    unsigned long long k = keys[i];
+    const KEY k = keys[i];
     if (i == 0 || keys[i - 1] != k) run_start[k] = (int)i;
 }
-__global__ void __launch_bounds__(256) k_cell_counts2(const unsigned long long *__restrict__ keys, int64_t n, const int *__restrict__ run_start,
+template <class KEY>
+__global__ void __launch_bounds__(256) k_cell_counts2(const KEY *__restrict__ keys, int64_t n, const int *__restrict__ run_start,
                                                       int *__restrict__ counts) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    unsigned long long k = keys[i];
+    const KEY k = keys[i];
     if (i == n - 1 || keys[i + 1] != k) counts[k] = (int)i + 1 - run_start[k];
 }
 
@@ -127,7 +131,8 @@ __global__ void __launch_bounds__(256) k_gather3(const double *__restrict__ src,
 
 // ------------------------------------------------------------------------------------------------ voxel
 // segment heads of the sorted key array -> compact list of segment starts (one output voxel per segment)
-__global__ void __launch_bounds__(256) k_seg_flags(const unsigned long long *__restrict__ keys, int64_t n, int *__restrict__ flags) {
+template <class KEY>
+__global__ void __launch_bounds__(256) k_seg_flags(const KEY *__restrict__ keys, int64_t n, int *__restrict__ flags) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     flags[i] = (i == 0 || keys[i - 1] != keys[i]) ? 1 : 0;
@@ -1260,7 +1265,8 @@ struct Grid {
     GridView v;
     int64_t n = 0;
     int64_t ncells = 0;
-    unsigned long long *keys = nullptr;  // sorted keys
+    void *keys = nullptr;   // sorted keys: unsigned if keys32, else unsigned long long
+    bool keys32 = false;
     double mn[3], mx[3];
 };
 
@@ -1284,15 +1290,28 @@ int cloud_bbox(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, doubl
     return R3D_OK;
 }
 
-// sorts point indices by cell key; fills keys_sorted / idx_sorted (device)
-int sort_by_cell(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, const double org[3], double cell, const int dims[3],
-                 int key_order, unsigned long long **keys_sorted, int **idx_sorted) {
-    unsigned long long *k0 = (unsigned long long *)ar.get((size_t)n * 8), *k1 = (unsigned long long *)ar.get((size_t)n * 8);
+// sorts point indices by cell key; fills keys_sorted / idx_sorted (device).  The keys are 32-bit whenever the key space allows
+// (the radix passes then move half the bytes); *keys32 tells the caller which type keys_sorted points to.
+template <class KEY>
+int sort_by_cell_t(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, const double org[3], double cell, const int dims[3],
+                   int key_order, int bits, void **keys_sorted, int **idx_sorted) {
+    KEY *k0 = (KEY *)ar.get((size_t)n * sizeof(KEY)), *k1 = (KEY *)ar.get((size_t)n * sizeof(KEY));
     int *v0 = (int *)ar.get((size_t)n * 4), *v1 = (int *)ar.get((size_t)n * 4);
     if (ar.rc) return ar.rc;
     const int nb = (int)((n + 255) / 256);
-    k_cell_keys<<<nb, 256, 0, ctx->stream>>>(d_pts, n, org[0], org[1], org[2], cell, dims[0], dims[1], dims[2], key_order, k0, v0);
+    k_cell_keys<KEY><<<nb, 256, 0, ctx->stream>>>(d_pts, n, org[0], org[1], org[2], cell, dims[0], dims[1], dims[2], key_order, k0, v0);
     R3D_HIP(ctx, hipGetLastError());
+    size_t tb = 0;
+    R3D_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k0, k1, v0, v1, (int)n, 0, bits, ctx->stream));
+    void *tmp = ar.get(tb);
+    if (ar.rc) return ar.rc;
+    R3D_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, tb, k0, k1, v0, v1, (int)n, 0, bits, ctx->stream));
+    *keys_sorted = k1;
+    *idx_sorted = v1;
+    return R3D_OK;
+}
+int sort_by_cell(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, const double org[3], double cell, const int dims[3],
+                 int key_order, void **keys_sorted, bool *keys32, int **idx_sorted) {
     int bits = 1;
     if (key_order == 2) {
         int m = std::max(dims[0], std::max(dims[1], dims[2])), b1 = 1;
@@ -1302,14 +1321,9 @@ int sort_by_cell(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, con
         const unsigned long long maxkey = (unsigned long long)dims[0] * dims[1] * dims[2];
         while (bits < 64 && (maxkey >> bits)) bits++;
     }
-    size_t tb = 0;
-    R3D_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k0, k1, v0, v1, (int)n, 0, bits, ctx->stream));
-    void *tmp = ar.get(tb);
-    if (ar.rc) return ar.rc;
-    R3D_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, tb, k0, k1, v0, v1, (int)n, 0, bits, ctx->stream));
-    *keys_sorted = k1;
-    *idx_sorted = v1;
-    return R3D_OK;
+    *keys32 = bits <= 32;
+    return *keys32 ? sort_by_cell_t<unsigned>(ctx, ar, d_pts, n, org, cell, dims, key_order, bits, keys_sorted, idx_sorted)
+                   : sort_by_cell_t<unsigned long long>(ctx, ar, d_pts, n, org, cell, dims, key_order, bits, keys_sorted, idx_sorted);
 }
 
 // Builds the search grid.  cell_hint: minimum useful cell (search radius, or <= 0 for pure kNN); the cell is
@@ -1342,7 +1356,7 @@ int grid_build(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, doubl
     G.n = n;
     G.ncells = (int64_t)dims[0] * dims[1] * dims[2];
     int *idx;
-    rc = sort_by_cell(ctx, ar, d_pts, n, G.mn, cell, dims, 0, &G.keys, &idx);
+    rc = sort_by_cell(ctx, ar, d_pts, n, G.mn, cell, dims, 0, &G.keys, &G.keys32, &idx);
     if (rc) return rc;
     int *cnt = (int *)ar.get((size_t)(G.ncells + 1) * 4), *rs = (int *)ar.get((size_t)(G.ncells + 1) * 4);
     int *cs = (int *)ar.get((size_t)(G.ncells + 1 + 4) * 4);   // + 4: nn_block_global reads 16 bytes at a run's first cell
@@ -1350,8 +1364,13 @@ int grid_build(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, doubl
     if (ar.rc) return ar.rc;
     R3D_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)(G.ncells + 1) * 4, ctx->stream));
     const int nb = (int)((n + 255) / 256);
-    k_cell_counts<<<nb, 256, 0, ctx->stream>>>(G.keys, n, rs, cnt);
-    k_cell_counts2<<<nb, 256, 0, ctx->stream>>>(G.keys, n, rs, cnt);
+    if (G.keys32) {
+        k_cell_counts<unsigned><<<nb, 256, 0, ctx->stream>>>((const unsigned *)G.keys, n, rs, cnt);
+        k_cell_counts2<unsigned><<<nb, 256, 0, ctx->stream>>>((const unsigned *)G.keys, n, rs, cnt);
+    } else {
+        k_cell_counts<unsigned long long><<<nb, 256, 0, ctx->stream>>>((const unsigned long long *)G.keys, n, rs, cnt);
+        k_cell_counts2<unsigned long long><<<nb, 256, 0, ctx->stream>>>((const unsigned long long *)G.keys, n, rs, cnt);
+    }
     {
         size_t tb = 0;
         R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, cs, (int)(G.ncells + 1), ctx->stream));
@@ -1677,14 +1696,16 @@ int voxel_segments(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, dou
         total *= dims[a];
     }
     if (total >= 1.8e19) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "voxel_downsample: voxel grid exceeds 2^64 cells");
-    unsigned long long *keys;
+    void *keys;
+    bool keys32;
     // key_order 1: exact legacy index floor((p - origin) / voxel), z fastest => output in lexicographic (kx,ky,kz) order
-    if ((rc = sort_by_cell(ctx, ar, d_p, n, org, voxel, dims, tensor_grid ? 3 : 1, &keys, &V.idx))) return rc;
+    if ((rc = sort_by_cell(ctx, ar, d_p, n, org, voxel, dims, tensor_grid ? 3 : 1, &keys, &keys32, &V.idx))) return rc;
     int *flags = (int *)ar.get((size_t)n * 4), *scan = (int *)ar.get((size_t)n * 4);
     V.starts = (int *)ar.get((size_t)n * 4);
     if (ar.rc) return ar.rc;
     const int nb = (int)((n + 255) / 256);
-    k_seg_flags<<<nb, 256, 0, ctx->stream>>>(keys, n, flags);
+    if (keys32) k_seg_flags<unsigned><<<nb, 256, 0, ctx->stream>>>((const unsigned *)keys, n, flags);
+    else k_seg_flags<unsigned long long><<<nb, 256, 0, ctx->stream>>>((const unsigned long long *)keys, n, flags);
     size_t tb = 0;
     R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flags, scan, (int)n, ctx->stream));
     void *tmp = ar.get(tb);
@@ -1769,9 +1790,10 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
         if (ar.rc) return ar.rc;
         k_transform<<<(unsigned)((ns + 255) / 256), 256, 0, ctx->stream>>>(d_s, ns, to_rigid(T), 0, d_s0);
         int dims[3] = {G.v.nx, G.v.ny, G.v.nz};
-        unsigned long long *sk;
+        void *sk;
+        bool sk32;
         int *sidx;
-        if ((rc = sort_by_cell(ctx, ar, d_s0, ns, G.mn, G.v.cell, dims, 2, &sk, &sidx))) return rc;
+        if ((rc = sort_by_cell(ctx, ar, d_s0, ns, G.mn, G.v.cell, dims, 2, &sk, &sk32, &sidx))) return rc;
         double *d_ss = (double *)ar.get((size_t)ns * 24);
         if (ar.rc) return ar.rc;
         k_gather3<<<(unsigned)((ns + 255) / 256), 256, 0, ctx->stream>>>(d_s, sidx, ns, d_ss);
