@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libr3d_hip.so")
 
 R3D_OK = 0
+HIP_STREAM_LEGACY = 1       # hipStreamLegacy ((hipStream_t)1, hip_runtime_api.h): the null stream with legacy synchronisation
 ERR_NAMES = {-1: "R3D_E_BADARG", -2: "R3D_E_HIP", -3: "R3D_E_OOM", -4: "R3D_E_UNSUPPORTED", -5: "R3D_E_NODEVICE"}
 
 
@@ -53,6 +54,8 @@ _SIGS = {
     "r3d_sgbm_compute": ([_vp, ctypes.POINTER(SgbmParams), _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp], ctypes.c_int),
     "r3d_sgbm_compute_dev": ([_vp, ctypes.POINTER(SgbmParams), _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp], ctypes.c_int),
     "r3d_sgbm_compute_batch_dev": ([_vp, ctypes.POINTER(SgbmParams), ctypes.c_int32, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp], ctypes.c_int),
+    "r3d_sgbm_compute_batch_events_dev": ([_vp, ctypes.POINTER(SgbmParams), ctypes.c_int32, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp], ctypes.c_int),
+    "r3d_stream_wait_event": ([_vp, _vp], ctypes.c_int),
     "r3d_filter_speckles": ([_vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32], ctypes.c_int),
     "r3d_set_profiling": ([_vp, ctypes.c_int], ctypes.c_int),
     "r3d_sgbm_profile": ([_vp, ctypes.POINTER(ctypes.c_float), ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32], ctypes.c_int),
@@ -182,7 +185,12 @@ class Context:
         self.call("r3d_sync")
 
     def set_stream(self, stream_ptr):
+        """stream_ptr: a hipStream_t handle as int; None / 0 = back to the context's own stream.  (The legacy null stream is
+        NOT reachable as 0: pass HIP_STREAM_LEGACY, or use distributed.shared_stream(), which never hands a 0 handle over.)"""
         self.call("r3d_set_stream", _vp(stream_ptr))
+
+    def get_stream(self):
+        return self._lib.r3d_get_stream(self._h) or 0
 
     def event(self):
         e = _vp()
@@ -191,6 +199,10 @@ class Context:
 
     def record(self, ev):
         self.call("r3d_event_record", _vp(ev))
+
+    def wait_event(self, ev):
+        """The context stream waits for the event (no host synchronisation)."""
+        self.call("r3d_stream_wait_event", _vp(ev))
 
     def elapsed_ms(self, a, b):
         ms = ctypes.c_float()

@@ -1,5 +1,6 @@
 // api.hip -- context, memory/timing helpers and the  extern "C" entry points declared in include/r3d.h.
 #include <dlfcn.h>
+#include <mutex>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
@@ -14,26 +15,27 @@ typedef int (*roctx_push_fn)(const char *);
 typedef int (*roctx_pop_fn)();
 roctx_push_fn g_roctx_push = nullptr;
 roctx_pop_fn g_roctx_pop = nullptr;
-int g_roctx_state = 0;   // 0: not looked up, 1: available, -1: unavailable / disabled
+std::once_flag g_roctx_once;   // one ctx per calling thread is the documented model: the lookup must be safe under concurrent first calls
 void roctx_lookup() {
-    g_roctx_state = -1;
     const char *e = getenv("R3D_ROCTX");
     if (e && !strcmp(e, "0")) return;
     for (const char *lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
         void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
         if (!h) continue;
-        g_roctx_push = (roctx_push_fn)dlsym(h, "roctxRangePushA");
-        g_roctx_pop = (roctx_pop_fn)dlsym(h, "roctxRangePop");
-        if (g_roctx_push && g_roctx_pop) { g_roctx_state = 1; return; }
+        roctx_push_fn pu = (roctx_push_fn)dlsym(h, "roctxRangePushA");
+        roctx_pop_fn po = (roctx_pop_fn)dlsym(h, "roctxRangePop");
+        if (pu && po) { g_roctx_pop = po; g_roctx_push = pu; return; }
     }
 }
 }  // namespace
-void r3d_roctx_push(const char *name) {
-    if (g_roctx_state == 0) roctx_lookup();
-    if (g_roctx_state == 1) (void)g_roctx_push(name);
+bool r3d_roctx_push(const char *name) {
+    std::call_once(g_roctx_once, roctx_lookup);   // both pointers are published before call_once returns on any thread
+    if (!g_roctx_push) return false;
+    (void)g_roctx_push(name);
+    return true;
 }
 void r3d_roctx_pop() {
-    if (g_roctx_state == 1) (void)g_roctx_pop();
+    if (g_roctx_pop) (void)g_roctx_pop();
 }
 
 
@@ -163,6 +165,12 @@ int r3d_set_stream(r3d_ctx *ctx, void *s) {
     return R3D_OK;
 }
 void *r3d_get_stream(r3d_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int r3d_stream_wait_event(r3d_ctx *ctx, void *ev) {
+    if (!ctx || !ev) return R3D_E_BADARG;
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    R3D_HIP(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)ev, 0));
+    return R3D_OK;
+}
 
 int r3d_debug_streambench(r3d_ctx *ctx, int32_t mode, int32_t rows, uint64_t row_bytes, int32_t write, int32_t delay, int32_t reps, float *ms) {
     R3D_ROCTX_RANGE("r3d_debug_streambench");
@@ -262,6 +270,12 @@ int r3d_sgbm_compute_dev(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *
 
 int r3d_sgbm_compute_batch_dev(r3d_ctx *ctx, const r3d_sgbm_params *p, int32_t n, const uint8_t *const *d_left,
                                const uint8_t *const *d_right, int32_t w, int32_t h, int32_t stride, int16_t *const *d_disp) {
+    return r3d_sgbm_compute_batch_events_dev(ctx, p, n, d_left, d_right, w, h, stride, d_disp, nullptr);
+}
+
+int r3d_sgbm_compute_batch_events_dev(r3d_ctx *ctx, const r3d_sgbm_params *p, int32_t n, const uint8_t *const *d_left,
+                                      const uint8_t *const *d_right, int32_t w, int32_t h, int32_t stride, int16_t *const *d_disp,
+                                      void *const *done_events) {
     R3D_ROCTX_RANGE("r3d_sgbm_compute_batch_dev");
     if (!ctx) return R3D_E_BADARG;
     if (n < 0 || (n > 0 && (!d_left || !d_right || !d_disp))) return r3d_fail(ctx, R3D_E_BADARG, "sgbm batch: bad argument");
@@ -281,6 +295,7 @@ int r3d_sgbm_compute_batch_dev(r3d_ctx *ctx, const r3d_sgbm_params *p, int32_t n
     for (int i = 0; i < n && rc == R3D_OK; i++) {
         const int l = i % lanes;
         rc = r3d_sgm_run(ctx, l, ctx->ws[l].stream, p, d_left[i], d_right[i], w, h, stride, d_disp[i]);
+        if (rc == R3D_OK && done_events && done_events[i]) R3D_HIP(ctx, hipEventRecord((hipEvent_t)done_events[i], ctx->ws[l].stream));
     }
     // join: the context stream continues after every lane has drained
     for (int l = 0; l < lanes; l++) {

@@ -1214,13 +1214,14 @@ __global__ void __launch_bounds__(256) k_reproject(const int16_t *__restrict__ d
 // ------------------------------------------------------------------------------------------------ depth image -> cloud
 // open3d.geometry.PointCloud.create_from_rgbd_image(RGBDImage.create_from_color_and_depth(color, depth, depth_scale, depth_trunc,
 // convert_rgb_to_intensity=False), intrinsic) followed by the flip of test/check84.py:155-159,172-178 -- the rule SURVEY.md
-// Appendix C verified on all 163 recorded frames: z = float(raw) / float(depth_scale) in FLOAT32, z > depth_trunc or z == 0
-// dropped, x = (u - ppx) z / fx, y = (v - ppy) z / fy in float64 (u = column, v = row), then (x, -y, -z); row-major pixel order;
+// Appendix C verified on all 163 recorded frames: z = float(raw) / float(depth_scale) in FLOAT32, (double)z >= depth_trunc
+// ([recalled] Image::ConvertDepthToFloatImage clips `*p >= depth_trunc`, the float promoted to the double parameter; the recorded
+// frames cannot tell >= from > because their scale 1/float(0.001) puts raw 3000 at 3.0000002) or z == 0 dropped, x = (u - ppx) z / fx, y = (v - ppy) z / fy in float64 (u = column, v = row), then (x, -y, -z); row-major pixel order;
 // colours = channel / 255.
-struct DepthCam { double fx, fy, ppx, ppy; float scale, trunc; int flip; };
+struct DepthCam { double fx, fy, ppx, ppy, trunc; float scale; int flip; };
 __device__ __forceinline__ float depth_z(unsigned short raw, const DepthCam &c) {
     const float z = (float)raw / c.scale;
-    return z > c.trunc ? 0.0f : z;
+    return (double)z >= c.trunc ? 0.0f : z;
 }
 __global__ void __launch_bounds__(256) k_depth_flags(const unsigned short *__restrict__ depth, int w, int stride, int64_t n, DepthCam c,
                                                      int *__restrict__ flags) {
@@ -1254,6 +1255,10 @@ struct DevArena {  // simple bump allocator over ctx->cloud_bufs (grow-only, reu
     explicit DevArena(r3d_ctx *c) : ctx(c) {}
     void *get(size_t bytes) {
         if (rc) return nullptr;
+        if (ctx->poisoned) {
+            rc = r3d_fail(ctx, R3D_E_HIP, "context poisoned by an earlier timed-out call (its kernels may still use the arena): destroy it");
+            return nullptr;
+        }
         if (next >= ctx->cloud_bufs.size()) ctx->cloud_bufs.emplace_back();
         r3d_buf &b = ctx->cloud_bufs[next++];
         rc = r3d_reserve(ctx, b, bytes ? bytes : 16);
@@ -1633,9 +1638,10 @@ int backproject_core(r3d_ctx *ctx, DevArena &ar, const uint16_t *depth, int w, i
     unsigned char *d_c = color ? (unsigned char *)ar.get((size_t)cstride * h) : nullptr;
     int *flags = (int *)ar.get((size_t)n * 4), *scan = (int *)ar.get((size_t)n * 4);
     if (ar.rc) return ar.rc;
-    R3D_HIP(ctx, hipMemcpyAsync(d_d, depth, (size_t)stride * h * 2, hipMemcpyHostToDevice, ctx->stream));
-    if (color) R3D_HIP(ctx, hipMemcpyAsync(d_c, color, (size_t)cstride * h, hipMemcpyHostToDevice, ctx->stream));
-    DepthCam c{cam->fx, cam->fy, cam->ppx, cam->ppy, (float)cam->depth_scale, (float)cam->depth_trunc, cam->flip_yz};
+    // the caller's last row need not be padded to the stride: (h-1) full strides + w elements is all that is guaranteed readable
+    R3D_HIP(ctx, hipMemcpyAsync(d_d, depth, ((size_t)stride * (h - 1) + w) * 2, hipMemcpyHostToDevice, ctx->stream));
+    if (color) R3D_HIP(ctx, hipMemcpyAsync(d_c, color, (size_t)cstride * (h - 1) + (size_t)w * 3, hipMemcpyHostToDevice, ctx->stream));
+    DepthCam c{cam->fx, cam->fy, cam->ppx, cam->ppy, cam->depth_trunc, (float)cam->depth_scale, cam->flip_yz};
     const int nb = (int)((n + 255) / 256);
     k_depth_flags<<<nb, 256, 0, ctx->stream>>>(d_d, w, stride, n, c, flags);
     size_t tb = 0;
@@ -1879,9 +1885,11 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
             if (q != hipErrorNotReady) return r3d_fail(ctx, R3D_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
             if ((spins & 63) != 63) continue;
             const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_poll).count();
-            if (waited > deadline_s)
+            if (waited > deadline_s) {
+                ctx->poisoned = true;   // the batch is still queued on arena buffers: no later call may reuse them
                 return r3d_fail(ctx, R3D_E_HIP, "registration loop: no completion after %.0f s (%d evaluations enqueued, last state read: %d evaluations, done=%d)",
                                 waited, enq, hst->evals, hst->done);
+            }
             if (waited > 2e-4) std::this_thread::sleep_for(std::chrono::microseconds(waited > 5e-3 ? 200 : 20));
         }
         if (hst->done) break;

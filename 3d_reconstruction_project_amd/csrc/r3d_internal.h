@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -14,6 +15,7 @@ struct r3d_buf {
 };
 
 #define R3D_MAX_PROF 16
+#define R3D_MAX_DEVICES 64   /* per-device caches of launch geometry */
 #define R3D_PROF_SETS 4
 
 struct r3d_prof_set {
@@ -46,6 +48,10 @@ struct r3d_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     bool profiling = false;
+    // set when a call gave up on work that is still queued on the stream (the registration loop's deadline): the arena and the
+    // workspaces that work uses must not be handed to another call, so every later compute call on this ctx fails (R3D_E_HIP)
+    // until it is destroyed
+    bool poisoned = false;
     // grow-only workspace
     r3d_buf img_l, img_r, out;
     r3d_sgm_ws ws[R3D_SGM_LANES];
@@ -112,11 +118,12 @@ static inline void r3d_prof_end(r3d_ctx *ctx, r3d_sgm_ws &ws, hipStream_t st) {
 // roctx ranges around every C-ABI entry point ("rocprofv3 --marker-trace attributes kernels to entry
 // points").  The marker library is looked up at run time (librocprofiler-sdk-roctx.so, the one rocprofv3 listens to, else the
 // legacy libroctx64.so); without it, or with R3D_ROCTX=0, a range is two predictable branches.
-void r3d_roctx_push(const char *name);
+bool r3d_roctx_push(const char *name);   // true if a range was opened (the scope pops only then: contexts live on several threads)
 void r3d_roctx_pop();
 struct r3d_roctx_scope {
-    explicit r3d_roctx_scope(const char *name) { r3d_roctx_push(name); }
-    ~r3d_roctx_scope() { r3d_roctx_pop(); }
+    bool pushed;
+    explicit r3d_roctx_scope(const char *name) : pushed(r3d_roctx_push(name)) {}
+    ~r3d_roctx_scope() { if (pushed) r3d_roctx_pop(); }
     r3d_roctx_scope(const r3d_roctx_scope &) = delete;
     r3d_roctx_scope &operator=(const r3d_roctx_scope &) = delete;
 };

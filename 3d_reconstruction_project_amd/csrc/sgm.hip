@@ -1738,16 +1738,18 @@ int launch_cost2_n(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t s
     const int tiles = tile_hi - tile_lo;
     if (tiles <= 0) return R3D_OK;
     // size the row bands so that one round of workgroups fills the chip (each band pays 2*SH2 extra rows of pixel cost)
-    static int per_cu = 0, cus = 0;   // queried once per instantiation (slab launches call this several times per map)
-    if (per_cu == 0) {
-        int v = 1;
+    // occupancy x CU count, queried once per instantiation AND device (slab launches call this several times per map; contexts of
+    // different devices / threads may race here: the slot is written once with a complete value, readers see 0 or that value)
+    static std::atomic<int> slots_of[R3D_MAX_DEVICES];
+    const int dev = ctx->device >= 0 && ctx->device < R3D_MAX_DEVICES ? ctx->device : 0;
+    int slots = slots_of[dev].load(std::memory_order_relaxed);
+    if (slots == 0) {
+        int v = 1, c = 256;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, (const void *)k_cost2<LPC, SH2, TRACK, VCH, NWAVE>, NWAVE * 64, 0);
-        per_cu = v < 1 ? 1 : v;
-        int c = 256;
         (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        cus = c < 1 ? 256 : c;
+        slots = (v < 1 ? 1 : v) * (c < 1 ? 256 : c);
+        slots_of[dev].store(slots, std::memory_order_relaxed);
     }
-    const int slots = per_cu * cus;
     int nb = slots / tiles;
     if (nb < 1) nb = 1;
     int BAND = (g.H + nb - 1) / nb;
@@ -1889,6 +1891,7 @@ int r3d_selftest_run(r3d_ctx *ctx) {
 int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p, const uint8_t *d_left, const uint8_t *d_right,
                 int w, int h, int stride, int16_t *d_disp) {
     r3d_sgm_ws &ws = ctx->ws[lane];
+    if (ctx->poisoned) return r3d_fail(ctx, R3D_E_HIP, "context poisoned by an earlier timed-out call: destroy it");
     SgmGeom g;
     if (int rc = derive_geom(ctx, p, w, h, g)) return rc;
     if (!d_left || !d_right || !d_disp) return r3d_fail(ctx, R3D_E_BADARG, "sgbm: null image pointer");

@@ -8,6 +8,8 @@ multi_view_fuse_tensors()  BASELINE config C5: one view per rank, ONE all-gather
                    HBM), every view registered to view 0, fused cloud on every rank (rank 0 hands it to the mesher,
                    mesh_reconstruction.py:22-37); multi_view_fuse() is its host-cloud front end.
 """
+import ctypes
+
 import numpy as np
 
 from . import cloud_ops, distributed
@@ -171,14 +173,57 @@ def view_to_cloud_tensors(d_left, d_right, d_disp, width, height, Q, matcher, ou
     """One stereo view whose images are already in HBM -> cloud left in HBM.  d_left / d_right / d_disp: device pointers
     (uint8 images, int16 disparity scratch); out: float64 torch tensor [2, capacity, 3] on the matcher's device that receives
     points (plane 0) and normals (plane 1).  Returns the tensor view out[:, :n] ([2, n, 3]).  Nothing crosses PCIe but the
-    point count.  Kernels run on the context stream (distributed.init() makes that torch's current stream)."""
+    point count.  The library kernels are ordered with torch's current stream (distributed.shared_stream): whatever torch
+    queued on the inputs before the call is seen, and torch ops / collectives queued on `out` afterwards see the cloud."""
     ctx = matcher.context
-    matcher.compute_device(d_left, d_right, width, height, width, d_disp)
-    cap = out.shape[1]
-    n = cloud_ops.disparity_to_cloud_resident(d_disp, width, height, Q, out[0].data_ptr(), out[1].data_ptr(), cap,
-                                              matcher.getMinDisparity(), max_depth, pose, voxel, normal_radius or 2 * voxel, max_nn,
-                                              ctx=ctx)
+    with distributed.shared_stream(ctx):
+        matcher.compute_device(d_left, d_right, width, height, width, d_disp)
+        cap = out.shape[1]
+        n = cloud_ops.disparity_to_cloud_resident(d_disp, width, height, Q, out[0].data_ptr(), out[1].data_ptr(), cap,
+                                                  matcher.getMinDisparity(), max_depth, pose, voxel, normal_radius or 2 * voxel,
+                                                  max_nn, ctx=ctx)
     return out[:, :n]
+
+
+def views_to_cloud_tensors(pairs, d_disps, width, height, Q, matcher, outs, cloud_ctx, voxel=0.01, normal_radius=None, max_nn=30,
+                           poses=None, max_depth=None):
+    """Several views owned by ONE GPU (a rank that holds more than one view of the C5 batch): the same results as one
+    view_to_cloud_tensors call per view, but the SGM maps go through the matcher's batch entry point (three maps in flight on
+    the library's lanes, r3d_sgbm_compute_batch_events_dev) and the cloud stages of view i (reprojection -> voxel grid ->
+    normals, on `cloud_ctx`, a second Context with its own stream and arena) start on map i's completion event, underneath the
+    SGM kernels of the later views.  pairs: [(d_left, d_right)] device pointers; d_disps: one int16 device buffer PER view;
+    outs: one [2, capacity, 3] float64 tensor per view.  Returns [out_i[:, :n_i]]."""
+    import torch
+    ctx = matcher.context
+    n = len(pairs)
+    assert len(d_disps) == n and len(outs) == n and cloud_ctx is not ctx
+    dev = outs[0].device
+    evs = [ctx.event() for _ in range(n)]
+    res = []
+    try:
+        with distributed.shared_stream(ctx) as sa:
+            sb = torch.cuda.Stream(device=dev)
+            sb.wait_stream(sa)
+            prev_b = cloud_ctx.get_stream()
+            cloud_ctx.set_stream(sb.cuda_stream)
+            try:
+                matcher.compute_batch_device([p[0] for p in pairs], [p[1] for p in pairs], width, height, width, list(d_disps),
+                                             done_events=evs)
+                for i in range(n):
+                    cloud_ctx.wait_event(evs[i])
+                    k = cloud_ops.disparity_to_cloud_resident(d_disps[i], width, height, Q, outs[i][0].data_ptr(), outs[i][1].data_ptr(),
+                                                              outs[i].shape[1], matcher.getMinDisparity(), max_depth,
+                                                              None if poses is None else poses[i], voxel, normal_radius or 2 * voxel,
+                                                              max_nn, ctx=cloud_ctx)
+                    res.append(outs[i][:, :k])
+                sa.wait_stream(sb)
+            finally:
+                cloud_ctx.set_stream(prev_b)
+    finally:
+        ctx.sync()
+        for e in evs:
+            ctx.call("r3d_event_destroy", ctypes.c_void_p(e))
+    return res
 
 
 def multi_view_fuse_tensors(local, n_views, threshold=0.02, mode=cloud_ops.GICP, max_iteration=30, register=None, transform=None,
@@ -200,6 +245,20 @@ def multi_view_fuse_tensors(local, n_views, threshold=0.02, mode=cloud_ops.GICP,
     if on_gpu and ctx is None:
         from . import _lib
         ctx = _lib.default_context(dev.index or 0)
+    if on_gpu:
+        # ONE stream for torch ops, RCCL collectives and library kernels for the whole exchange (the context's own
+        # stream is not ordered against torch's)
+        outer = torch.cuda.current_stream(dev)
+        with distributed.shared_stream(ctx):
+            fused, Ts = _multi_view_fuse_on_stream(local, n_views, threshold, mode, max_iteration, register, transform, ctx, timings, dev)
+        fused.record_stream(outer)
+        return fused, Ts
+    return _multi_view_fuse_on_stream(local, n_views, threshold, mode, max_iteration, register, transform, ctx, timings, dev)
+
+
+def _multi_view_fuse_on_stream(local, n_views, threshold, mode, max_iteration, register, transform, ctx, timings, dev):
+    import torch
+    on_gpu = dev.type == "cuda"
 
     def mark():
         if not on_gpu:
@@ -221,15 +280,20 @@ def multi_view_fuse_tensors(local, n_views, threshold=0.02, mode=cloud_ops.GICP,
     ref = everyone[0]
     mine = {}
     for v in local:
-        if v == 0:
-            T = np.eye(4)
-        elif register is not None:
-            T = np.asarray(register(everyone[v], ref), dtype=np.float64)
-        else:
-            src = everyone[v]
-            T = cloud_ops.registration_device(src[0].data_ptr(), src.shape[1], ref[0].data_ptr(), ref.shape[1], threshold, mode=mode,
-                                              max_iteration=max_iteration, d_source_normals=src[1].data_ptr(),
-                                              d_target_normals=ref[1].data_ptr(), ctx=ctx)["T"]
+        # a registration that fails on this rank must not strand the others in the next collective: the exception travels as
+        # a flag through gather_transforms, which then raises on every rank together
+        try:
+            if v == 0:
+                T = np.eye(4)
+            elif register is not None:
+                T = np.asarray(register(everyone[v], ref), dtype=np.float64)
+            else:
+                src = everyone[v]
+                T = cloud_ops.registration_device(src[0].data_ptr(), src.shape[1], ref[0].data_ptr(), ref.shape[1], threshold,
+                                                  mode=mode, max_iteration=max_iteration, d_source_normals=src[1].data_ptr(),
+                                                  d_target_normals=ref[1].data_ptr(), ctx=ctx)["T"]
+        except Exception as e:  # noqa: BLE001
+            T = e
         mine[v] = T
     t2 = mark()
     Ts = distributed.gather_transforms(mine, n_views)

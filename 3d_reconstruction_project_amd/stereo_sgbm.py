@@ -82,14 +82,20 @@ class StereoSGBM:
         self.context.call("r3d_sgbm_compute_dev", ctypes.byref(p), vp(d_left), vp(d_right), int(width), int(height),
                           int(stride), vp(d_disp))
 
-    def compute_batch_device(self, d_lefts, d_rights, width, height, stride, d_disps):
-        """Device-pointer batch (lists of ints): maps are pipelined over the library's internal lanes."""
+    def compute_batch_device(self, d_lefts, d_rights, width, height, stride, d_disps, done_events=None):
+        """Device-pointer batch (lists of ints): maps are pipelined over the library's internal lanes.  done_events (list of
+        Context.event() handles or None entries): map i's completion is recorded into done_events[i], so a consumer on another
+        context can wait for it (Context.wait_event) while later maps are still running."""
         n = len(d_lefts)
-        assert len(d_rights) == n and len(d_disps) == n
+        assert len(d_rights) == n and len(d_disps) == n and (done_events is None or len(done_events) == n)
         arr = ctypes.c_void_p * n
         p = self.params_struct()
-        self.context.call("r3d_sgbm_compute_batch_dev", ctypes.byref(p), n, arr(*d_lefts), arr(*d_rights), int(width),
-                          int(height), int(stride), arr(*d_disps))
+        if done_events is None:
+            self.context.call("r3d_sgbm_compute_batch_dev", ctypes.byref(p), n, arr(*d_lefts), arr(*d_rights), int(width),
+                              int(height), int(stride), arr(*d_disps))
+        else:
+            self.context.call("r3d_sgbm_compute_batch_events_dev", ctypes.byref(p), n, arr(*d_lefts), arr(*d_rights), int(width),
+                              int(height), int(stride), arr(*d_disps), arr(*done_events))
 
     def compute_batch(self, lefts, rights):
         """lefts / rights: sequences of uint8 [H,W] images of equal size -> list of int16 disparity maps."""

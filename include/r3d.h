@@ -37,8 +37,14 @@ int r3d_init(int device, r3d_ctx **out);
 void r3d_destroy(r3d_ctx *ctx);
 const char *r3d_last_error(const r3d_ctx *ctx); /* ctx may be NULL: returns the last r3d_init error */
 int r3d_sync(r3d_ctx *ctx);                     /* hipStreamSynchronize on the ctx stream */
-int r3d_set_stream(r3d_ctx *ctx, void *hip_stream /* hipStream_t, NULL = ctx-owned stream */);
+/* hip_stream: a hipStream_t.  NULL = back to the ctx-owned stream (created hipStreamNonBlocking: NOT ordered against the null
+ * stream).  The legacy null stream is therefore not selectable as 0: pass hipStreamLegacy ((hipStream_t)1) for it, or -- what the
+ * Python layer does (distributed.shared_stream) -- make a named stream current on the caller's side and pass that. */
+int r3d_set_stream(r3d_ctx *ctx, void *hip_stream);
 void *r3d_get_stream(r3d_ctx *ctx);
+/* the ctx stream waits for a hipEvent_t (created by r3d_event_create on any ctx of this device, or by the caller): the join
+ * between two contexts / streams without a host synchronisation */
+int r3d_stream_wait_event(r3d_ctx *ctx, void *hip_event);
 /* diagnostic: prices an access shape (rows independent streams of row_bytes; mode 0 = 256 B, 1 = 1 KB per wave request) */
 int r3d_debug_streambench(r3d_ctx *ctx, int32_t mode, int32_t rows, uint64_t row_bytes, int32_t write, int32_t delay, int32_t reps, float *ms);
 /* checks the cross-lane primitives (DPP shifts, permlane swaps, wave reductions) the kernels rely on */
@@ -87,6 +93,12 @@ int r3d_sgbm_compute_dev(r3d_ctx *ctx, const r3d_sgbm_params *p, const uint8_t *
  * forks from / joins into the ctx stream, i.e. to the caller it behaves like n r3d_sgbm_compute_dev calls. */
 int r3d_sgbm_compute_batch_dev(r3d_ctx *ctx, const r3d_sgbm_params *p, int32_t n, const uint8_t *const *d_left,
                                const uint8_t *const *d_right, int32_t w, int32_t h, int32_t stride, int16_t *const *d_disp);
+/* the same, and map i's completion is recorded into done_events[i] (hipEvent_t, may be NULL per entry) on the lane that ran it:
+ * a consumer on ANOTHER stream / context (r3d_stream_wait_event) can start on map i while later maps are still in flight
+ * (the C5 view chain on one GPU: the cloud stages of view i run underneath the SGM kernels of views i+1 ...) */
+int r3d_sgbm_compute_batch_events_dev(r3d_ctx *ctx, const r3d_sgbm_params *p, int32_t n, const uint8_t *const *d_left,
+                                      const uint8_t *const *d_right, int32_t w, int32_t h, int32_t stride, int16_t *const *d_disp,
+                                      void *const *done_events);
 
 /* cv2.filterSpeckles(img, newVal, maxSpeckleSize, maxDiff) on an int16 image, in place (host buffer): the last stage of
  * StereoSGBM.compute when speckleWindowSize > 0 (Calib_depth/depth4.py:164-165, depth_test.py:170-171) */

@@ -72,10 +72,12 @@ DEPTH_SCALE_F32 = np.float32(1.0) / np.float32(0.001)      # check84.py:158: 1.0
 
 
 def backproject(depth_u16, intr, depth_scale=DEPTH_SCALE_F32, depth_trunc=3.0, flip=True):
-    """Appendix C of SURVEY.md (fixture-verified): z = f32(raw)/f32(scale), z > trunc or z == 0 dropped,
-    x=(u-ppx)*z/fx, y=(v-ppy)*z/fy in float64, then (x,-y,-z); row-major pixel order.  Returns (points, (v,u))."""
+    """Appendix C of SURVEY.md (fixture-verified): z = f32(raw)/f32(scale), z >= trunc or z == 0 dropped,
+    x=(u-ppx)*z/fx, y=(v-ppy)*z/fy in float64, then (x,-y,-z); row-major pixel order.  Returns (points, (v,u)).
+    [recalled] Image::ConvertDepthToFloatImage clips `*p >= depth_trunc` with the float promoted to the double parameter; the
+    recorded frames agree with both >= and > (their scale puts raw 3000 at 3.0000002)."""
     z = (depth_u16.astype(np.float32) / np.float32(depth_scale)).astype(np.float32)
-    z[z > np.float32(depth_trunc)] = 0
+    z[z.astype(np.float64) >= float(depth_trunc)] = 0
     v, u = np.nonzero(z > 0)
     zz = z[v, u].astype(np.float64)
     x = (u - intr["ppx"]) * zz / intr["fx"]

@@ -560,6 +560,17 @@ def test_backproject_depth_reproduces_recorded_ply(r3d, sub, frame):
     assert r3d.cloud_ops.backproject_depth(np.zeros((4, 5), np.uint16), cam)[0].shape == (0, 3)
 
 
+def test_backproject_depth_exactly_at_the_truncation(r3d):
+    """a depth exactly at depth_trunc is dropped (`>=` in double, as the original)."""
+    d = np.array([[2999, 3000, 3001, 0]], np.uint16)
+    for trunc in (3.0, 3.0005):
+        cam = r3d.cloud_ops.depth_camera(INTR, depth_scale=1000.0, depth_trunc=trunc)
+        got, _ = r3d.cloud_ops.backproject_depth(d, cam)
+        want, _ = co.backproject(d, INTR, depth_scale=1000.0, depth_trunc=trunc)
+        np.testing.assert_array_equal(got, want)
+        assert len(got) == (1 if trunc == 3.0 else 2)
+
+
 def test_scanning_loop_from_depth_images_equals_loop_over_clouds(r3d):
     """main.py:34-54 fed with the recorded depth PNGs (back-projection on the device, model in HBM) == the same loop over the
     oracle's back-projected clouds, colours included; failed captures (None, all-zero, everything beyond depth_trunc) are skipped."""

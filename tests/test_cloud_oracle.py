@@ -65,6 +65,16 @@ def test_depth_scale_subtlety():
     assert float(co.DEPTH_SCALE_F32) != 1000.0 and abs(float(co.DEPTH_SCALE_F32) - 999.99994) < 1e-4
 
 
+def test_depth_exactly_at_the_truncation_is_dropped():
+    """[recalled] ConvertDepthToFloatImage zeroes `*p >= depth_trunc` (float promoted to double).  With depth_scale = 1000 a raw
+    3000 is exactly 3.0: dropped; 2999 is kept.  (the recorded frames cannot tell >= from >.)"""
+    d = np.array([[2999, 3000, 3001, 0]], np.uint16)
+    pts, (v, u) = co.backproject(d, INTR, depth_scale=1000.0, depth_trunc=3.0)
+    assert list(u) == [0] and abs(pts[0, 2] + 2.999) < 1e-6
+    pts, (v, u) = co.backproject(d, INTR, depth_scale=1000.0, depth_trunc=3.0005)     # float32(3.0) < 3.0005 < float32(3.001)
+    assert list(u) == [0, 1]
+
+
 def _sphere(n, seed, r=1.0):
     rng = np.random.default_rng(seed)
     v = rng.standard_normal((n, 3))

@@ -72,6 +72,22 @@ def _worker(rank, world, port, n_views, q):
             assert np.abs(Ts[v][:3, 3] - shifts[v]).max() < 1e-12
         assert len(fused.points) == sum(400 + 10 * v for v in range(n_views)) and fused.has_normals()
         assert np.abs(fused.points[:400] - base[:400]).max() < 1e-12      # every view lands back on the base patch
+        # --- a registration that fails on ONE rank surfaces on EVERY rank at the same point (no rank is left in a collective)
+        def bad_register(src, tgt):
+            if rank == world - 1:
+                raise ValueError("synthetic failure")
+            return np.eye(4)
+        try:
+            r3d.pipeline.multi_view_fuse(clouds, n_views, register=bad_register)
+            raise AssertionError("expected RemoteStageError on every rank")
+        except D.RemoteStageError as e:
+            assert ("synthetic failure" in str(e)) == (rank == world - 1)
+        D.agree(True, "nothing")
+        try:
+            D.agree(True if rank != 0 else KeyError("x"), "stage A")
+            raise AssertionError("expected RemoteStageError on every rank")
+        except D.RemoteStageError as e:
+            assert "rank(s) [0]" in str(e)
         q.put((rank, "ok", float(fused.points.sum())))
         dist.barrier()
         dist.destroy_process_group()
@@ -117,3 +133,40 @@ def test_pointcloud_container_semantics(r3d):
     e = r3d.PointCloud()
     e += b
     assert e.has_normals() and e.has_colors() and len(e) == 3
+
+
+def _run_bench(*extra, timeout=240):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *extra], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, timeout=timeout, env=env)
+
+
+def test_bench_gpus_n_launches_n_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it must start 2 ranks as fresh child processes (before any GPU call),
+    bind them to LOCAL_RANK 0 / 1, and relay rank 0's single JSON line: control flow only (--dry-control, gloo, no GPU)."""
+    import json
+    r = _run_bench("--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-control", "--backend", "gloo")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                                   # exactly ONE line on stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1 and out["dry_control"] is True
+    ranks = sorted(out["ranks"], key=lambda d: d["rank"])
+    assert [d["rank"] for d in ranks] == [0, 1] and [d["local_rank"] for d in ranks] == [0, 1]
+    assert len({d["pid"] for d in ranks}) == 2 and all(d["pid"] != os.getpid() for d in ranks)
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr      # the child command line
+
+
+def test_bench_launcher_propagates_a_failed_rank():
+    r = _run_bench("--gpus", "2", "--dry-control", "--backend", "gloo", "--dry-fail-rank", "1")
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-control"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
