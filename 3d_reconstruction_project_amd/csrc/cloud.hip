@@ -384,52 +384,114 @@ __device__ __forceinline__ int knn_query(const GridView &g, double qx, double qy
     return cnt;
 }
 
-// symmetric 3x3 eigen-decomposition (cyclic Jacobi, float64); returns the eigenvector of the smallest eigenvalue
-__device__ __forceinline__ void smallest_eigvec(double a00, double a01, double a02, double a11, double a12, double a22, double n[3]) {
-    double A[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
-    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    // the annihilated element is set to exactly zero and the stop is relative: 4-6 sweeps (an absolute 1e-300 is never
-    // reached because of the rounding residue of each rotation, so all 12 sweeps used to run)
-    for (int sweep = 0; sweep < 12; sweep++) {
-        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]), scale = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
-        if (off < 1e-300 || off <= 1e-30 * scale) break;
-#pragma unroll
-        for (int pq = 0; pq < 3; pq++) {
-            const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
-            if (fabs(A[p][q]) <= 1e-33 * scale) { A[p][q] = A[q][p] = 0; continue; }
-            double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-            double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {  // A <- A J
-                double akp = A[k][p], akq = A[k][q];
-                A[k][p] = c * akp - s * akq;
-                A[k][q] = s * akp + c * akq;
-            }
-#pragma unroll
-            for (int k = 0; k < 3; k++) {  // A <- J^T A
-                double apk = A[p][k], aqk = A[q][k];
-                A[p][k] = c * apk - s * aqk;
-                A[q][k] = s * apk + c * aqk;
-            }
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                double vkp = V[k][p], vkq = V[k][q];
-                V[k][p] = c * vkp - s * vkq;
-                V[k][q] = s * vkp + c * vkq;
-            }
-            A[p][q] = A[q][p] = 0;
-        }
+// Normal of a neighbourhood covariance as legacy Open3D computes it: FastEigen3x3 [recalled: geometry/EstimateNormals.cpp, the
+// closed form of geometrictools' RobustEigenSymmetric3x3] -- eigenvalues from the trigonometric solution of the characteristic
+// cubic of A = cov / max coefficient, the eigenvector of the better-conditioned extreme eigenvalue from the largest cross product
+// of two rows of A - lambda I, the middle one from the 2x2 problem in its orthogonal complement, the third as their cross
+// product; returns the eigenvector of the smallest eigenvalue WITH THE SIGN THE FORMULAS PRODUCE (the reference's recorded
+// normals carry exactly that sign).  The fused multiply-adds are placed explicitly (the library is built with
+// -ffp-contract=off): they are the ones of the build that recorded the reference's frames, found by matching its 2.14 M recorded
+// normals (oracle/normals.c header, profiles/r03_pin_normals.json: 89 % bit-equal sign included, all within 2e-12).  Cheaper
+// than the cyclic Jacobi sweeps it replaces, and a degenerate neighbourhood now has the answer the original's formulas give.
+__device__ __forceinline__ double fe_mulsub(double a, double b, double c, double d) { return fma(a, b, -(c * d)); }   // a*b - c*d
+__device__ __forceinline__ void fe_cross(const double a[3], const double b[3], double o[3]) {
+    o[0] = fe_mulsub(a[1], b[2], a[2], b[1]);
+    o[1] = fe_mulsub(a[2], b[0], a[0], b[2]);
+    o[2] = fe_mulsub(a[0], b[1], a[1], b[0]);
+}
+__device__ __forceinline__ void fe_eigenvector0(const double A[6], double ev, double o[3]) {
+    const double r0[3] = {A[0] - ev, A[1], A[2]}, r1[3] = {A[1], A[3] - ev, A[4]}, r2[3] = {A[2], A[4], A[5] - ev};
+    double c01[3], c02[3], c12[3];
+    fe_cross(r0, r1, c01);
+    fe_cross(r0, r2, c02);
+    fe_cross(r1, r2, c12);
+    const double d0 = fma(c01[2], c01[2], c01[0] * c01[0] + c01[1] * c01[1]);    // Eigen's 3-vector dot: packet of two + scalar tail
+    const double d1 = fma(c02[2], c02[2], c02[0] * c02[0] + c02[1] * c02[1]);
+    const double d2 = fma(c12[2], c12[2], c12[0] * c12[0] + c12[1] * c12[1]);
+    // imax as the original: d1 replaces d0 if larger, d2 replaces the running maximum if larger (static selects only)
+    const bool s1 = d1 > d0;
+    const double dm = s1 ? d1 : d0;
+    const bool s2 = d2 > dm;
+    const double x = s2 ? c12[0] : (s1 ? c02[0] : c01[0]), y = s2 ? c12[1] : (s1 ? c02[1] : c01[1]), z = s2 ? c12[2] : (s1 ? c02[2] : c01[2]);
+    const double l = sqrt(s2 ? d2 : dm);
+    o[0] = x / l; o[1] = y / l; o[2] = z / l;
+}
+__device__ __forceinline__ void fe_eigenvector1(const double A[6], const double e0[3], double ev1, double o[3]) {
+    double U[3], V[3];
+    if (fabs(e0[0]) > fabs(e0[1])) {
+        const double il = 1.0 / sqrt(fma(e0[0], e0[0], e0[2] * e0[2]));
+        U[0] = -e0[2] * il; U[1] = 0.0; U[2] = e0[0] * il;
+    } else {
+        const double il = 1.0 / sqrt(fma(e0[1], e0[1], e0[2] * e0[2]));
+        U[0] = 0.0; U[1] = e0[2] * il; U[2] = -e0[1] * il;
     }
-    // static selects only (a runtime column index would push V to scratch memory)
-    const bool m1 = A[1][1] < A[0][0];
-    const double e01 = m1 ? A[1][1] : A[0][0];
-    const bool m2 = A[2][2] < e01;
-    double x = m2 ? V[0][2] : (m1 ? V[0][1] : V[0][0]);
-    double y = m2 ? V[1][2] : (m1 ? V[1][1] : V[1][0]);
-    double z = m2 ? V[2][2] : (m1 ? V[2][1] : V[2][0]);
-    double l = sqrt(x * x + y * y + z * z);
-    n[0] = x / l; n[1] = y / l; n[2] = z / l;
+    fe_cross(e0, U, V);
+#define FE_SUM3(x0, y0, x1, y1, x2, y2) fma((x2), (y2), fma((x0), (y0), (x1) * (y1)))
+    const double AU[3] = {FE_SUM3(A[0], U[0], A[1], U[1], A[2], U[2]), FE_SUM3(A[1], U[0], A[3], U[1], A[4], U[2]),
+                          FE_SUM3(A[2], U[0], A[4], U[1], A[5], U[2])};
+    const double AV[3] = {FE_SUM3(A[0], V[0], A[1], V[1], A[2], V[2]), FE_SUM3(A[1], V[0], A[3], V[1], A[4], V[2]),
+                          FE_SUM3(A[2], V[0], A[4], V[1], A[5], V[2])};
+    double m00 = FE_SUM3(U[0], AU[0], U[1], AU[1], U[2], AU[2]) - ev1;
+    double m01 = FE_SUM3(U[0], AV[0], U[1], AV[1], U[2], AV[2]);
+    double m11 = FE_SUM3(V[0], AV[0], V[1], AV[1], V[2], AV[2]) - ev1;
+#undef FE_SUM3
+    const double a00 = fabs(m00), a01 = fabs(m01), a11 = fabs(m11);
+    double cu, cv;   // result = cu * U - cv * V
+    if (a00 >= a11) {
+        if (!(fmax(a00, a01) > 0)) { o[0] = U[0]; o[1] = U[1]; o[2] = U[2]; return; }
+        if (a00 >= a01) { m01 /= m00; m00 = 1.0 / sqrt(fma(m01, m01, 1.0)); m01 *= m00; }
+        else { m00 /= m01; m01 = 1.0 / sqrt(fma(m00, m00, 1.0)); m00 *= m01; }
+        cu = m01; cv = m00;
+    } else {
+        if (!(fmax(a11, a01) > 0)) { o[0] = U[0]; o[1] = U[1]; o[2] = U[2]; return; }
+        if (a11 >= a01) { m01 /= m11; m11 = 1.0 / sqrt(fma(m01, m01, 1.0)); m01 *= m11; }
+        else { m11 /= m01; m01 = 1.0 / sqrt(fma(m11, m11, 1.0)); m11 *= m01; }
+        cu = m11; cv = m01;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) o[i] = fe_mulsub(cu, U[i], cv, V[i]);
+}
+// cov as c00 c01 c02 c11 c12 c22; n = (0,0,0) for an all-zero matrix (the caller substitutes (0,0,1) / the previous normal)
+__device__ __forceinline__ void fast_eigen3x3(double c00, double c01, double c02, double c11, double c12, double c22, double n[3]) {
+    const double mx = fmax(fmax(fmax(c00, c01), fmax(c02, c11)), fmax(c12, c22));
+    n[0] = n[1] = n[2] = 0.0;
+    if (mx == 0.0) return;
+    const double A[6] = {c00 / mx, c01 / mx, c02 / mx, c11 / mx, c12 / mx, c22 / mx};
+    const double norm = (A[1] * A[1] + A[2] * A[2]) + A[4] * A[4];
+    if (!(norm > 0.0)) {   // diagonal matrix: the axis of the strictly smallest diagonal entry, z otherwise
+        const double a00 = A[0] * mx, a11 = A[3] * mx, a22 = A[5] * mx;
+        if (a00 < a11 && a00 < a22) n[0] = 1.0;
+        else if (a11 < a00 && a11 < a22) n[1] = 1.0;
+        else n[2] = 1.0;
+        return;
+    }
+    const double q = (A[0] + A[3] + A[5]) / 3.0;
+    const double b00 = A[0] - q, b11 = A[3] - q, b22 = A[5] - q;
+    const double p = sqrt(fma(norm, 2.0, fma(b22, b22, fma(b00, b00, b11 * b11))) / 6.0);
+    const double k00 = fe_mulsub(b11, b22, A[4], A[4]);
+    const double k01 = fe_mulsub(A[1], b22, A[4], A[2]);
+    const double k02 = fe_mulsub(A[1], A[4], b11, A[2]);
+    const double det = fma(A[2], k02, fma(b00, k00, -(A[1] * k01))) / (p * p * p);
+    const double half_det = fmin(fmax(det * 0.5, -1.0), 1.0);
+    const double angle = acos(half_det) / 3.0;
+    const double beta2 = cos(angle) * 2.0;
+    const double beta0 = cos(angle + 2.09439510239319549) * 2.0;
+    const double beta1 = -(beta0 + beta2);
+    const double e0 = fma(p, beta0, q), e1 = fma(p, beta1, q), e2 = fma(p, beta2, q);
+    double va[3], vb[3];
+    if (half_det >= 0.0) {
+        fe_eigenvector0(A, e2, va);                                    // evec2
+        if (e2 < e0 && e2 < e1) { n[0] = va[0]; n[1] = va[1]; n[2] = va[2]; return; }
+        fe_eigenvector1(A, va, e1, vb);                                // evec1
+        if (e1 < e0 && e1 < e2) { n[0] = vb[0]; n[1] = vb[1]; n[2] = vb[2]; return; }
+        fe_cross(vb, va, n);                                           // evec0 = evec1 x evec2
+    } else {
+        fe_eigenvector0(A, e0, va);                                    // evec0
+        if (e0 < e1 && e0 < e2) { n[0] = va[0]; n[1] = va[1]; n[2] = va[2]; return; }
+        fe_eigenvector1(A, va, e1, vb);                                // evec1
+        if (e1 < e0 && e1 < e2) { n[0] = vb[0]; n[1] = vb[1]; n[2] = vb[2]; return; }
+        fe_cross(va, vb, n);                                           // evec2 = evec0 x evec1
+    }
 }
 
 // k_normals: one thread per (cell-sorted) point: hybrid / kNN search, population covariance, smallest eigenvector.
@@ -444,10 +506,13 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_normals(GridView g, int64_t n, in
     const int t = threadIdx.x;
     const double qx = g.pts[i * 3], qy = g.pts[i * 3 + 1], qz = g.pts[i * 3 + 2];
     const int cnt = knn_query(g, qx, qy, qz, k, radius, sd, si);
-    double nrm[3] = {0.0, 0.0, 1.0};
+    // utility::ComputeCovariance [recalled]: ONE pass of nine cumulants over the RAW coordinates in neighbour order (nearest
+    // first), products accumulated with fused multiply-adds, divided by the count, cov = E[ab] - E[a] E[b] (fused); fewer than
+    // 3 neighbours: identity covariance, whose "normal" is (0,0,1).  Pinned by the recorded frames (oracle/normals.c).
+    double nrm[3] = {0.0, 0.0, 0.0};
     if (cnt >= 3) {
         double sx = 0, sy = 0, sz = 0, xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
-        for (int j0 = 0; j0 < cnt; j0 += 4) {       // four neighbours per round trip, summed in list order as before
+        for (int j0 = 0; j0 < cnt; j0 += 4) {       // four neighbours per round trip, summed in list order
             double X[4], Y[4], Z[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -457,25 +522,22 @@ __global__ void __launch_bounds__(KNN_BLOCK) k_normals(GridView g, int64_t n, in
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (j0 + u >= cnt) break;
-                const double x = X[u] - qx, y = Y[u] - qy, z = Z[u] - qz;  // centred on the query
+                const double x = X[u], y = Y[u], z = Z[u];
                 sx += x; sy += y; sz += z;
-                xx += x * x; xy += x * y; xz += x * z; yy += y * y; yz += y * z; zz += z * z;
+                xx = fma(x, x, xx); xy = fma(x, y, xy); xz = fma(x, z, xz); yy = fma(y, y, yy); yz = fma(y, z, yz); zz = fma(z, z, zz);
             }
         }
-        const double inv = 1.0 / cnt;
-        sx *= inv; sy *= inv; sz *= inv;
-        smallest_eigvec(xx * inv - sx * sx, xy * inv - sx * sy, xz * inv - sx * sz, yy * inv - sy * sy, yz * inv - sy * sz,
-                        zz * inv - sz * sz, nrm);
+        const double dn = (double)cnt;
+        sx /= dn; sy /= dn; sz /= dn; xx /= dn; xy /= dn; xz /= dn; yy /= dn; yz /= dn; zz /= dn;
+        fast_eigen3x3(fma(-sx, sx, xx), fma(-sx, sy, xy), fma(-sx, sz, xz), fma(-sy, sy, yy), fma(-sy, sz, yz), fma(-sz, sz, zz), nrm);
     }
     const int64_t o = g.idx[i];
-    bool flip;
-    if (prev) flip = nrm[0] * prev[o * 3] + nrm[1] * prev[o * 3 + 1] + nrm[2] * prev[o * 3 + 2] < 0;
-    else {  // sign convention (an eigenvector's sign is solver-dependent): largest-magnitude component positive
-        const double ax = fabs(nrm[0]), ay = fabs(nrm[1]), az = fabs(nrm[2]);
-        const double lead = (ax >= ay && ax >= az) ? nrm[0] : (ay >= az ? nrm[1] : nrm[2]);
-        flip = lead < 0;
-    }
-    if (flip) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
+    const bool zero = nrm[0] == 0.0 && nrm[1] == 0.0 && nrm[2] == 0.0;     // < 3 neighbours or an all-zero covariance
+    if (prev) {   // a cloud that already carries normals: a zero result keeps the old normal, every other one is turned towards it
+        const double px = prev[o * 3], py = prev[o * 3 + 1], pz = prev[o * 3 + 2];
+        if (zero) { nrm[0] = px; nrm[1] = py; nrm[2] = pz; }
+        if ((nrm[0] * px + nrm[1] * py) + nrm[2] * pz < 0) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
+    } else if (zero) nrm[2] = 1.0;
     normals[o * 3] = nrm[0]; normals[o * 3 + 1] = nrm[1]; normals[o * 3 + 2] = nrm[2];
     if (nn_count) nn_count[o] = cnt;
 }

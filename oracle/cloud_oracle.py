@@ -152,33 +152,63 @@ def _d2(points, idx, q):
     return (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
 
 
-def _pca_normals(points, idx_lists, prev_normals=None, centers=None):
-    """Population covariance of every neighbour list (centred on the query first, as the kernel and Open3D's cumulant
-    form do), eigenvector of the smallest eigenvalue; fewer than 3 neighbours -> (0,0,1).  Sign: towards prev_normals
-    when given (legacy EstimateNormals keeps an existing orientation), else the canonical one of _canon_sign."""
-    centers = points if centers is None else centers
-    n = centers.shape[0]
-    cnt = np.fromiter((len(ix) for ix in idx_lists), np.int64, n)
-    kmax = int(cnt.max()) if n else 0
-    pad = np.zeros((n, max(kmax, 1)), np.int64)
-    mask = np.arange(max(kmax, 1))[None, :] < cnt[:, None]
+def _normals_lib():
+    import ctypes
+    from . import sgbm_oracle
+    L = ctypes.CDLL(sgbm_oracle.build())
+    dp, i64p, i32p = (ctypes.POINTER(t) for t in (ctypes.c_double, ctypes.c_int64, ctypes.c_int32))
+    L.r3d_oracle_cumulant_cov.argtypes = [dp, i64p, i32p, ctypes.c_int64, ctypes.c_int32, i32p, dp]
+    L.r3d_oracle_cumulant_cov.restype = None
+    L.r3d_oracle_fast_eigen3x3.argtypes = [dp, ctypes.c_int64, i32p, dp]
+    L.r3d_oracle_fast_eigen3x3.restype = None
+    return L, dp, i64p, i32p
+
+
+def cumulant_covariances(points, idx_lists, cfg=None):
+    """utility::ComputeCovariance of every neighbour list (oracle/normals.c: one pass of nine cumulants over the raw
+    coordinates, nearest neighbour first); identity where a list has fewer than 3 entries (EstimatePerPointCovariances)."""
+    L, dp, i64p, i32p = _normals_lib()
+    n = len(idx_lists)
+    cnt = np.fromiter((len(ix) for ix in idx_lists), np.int32, n)
+    k = max(int(cnt.max()) if n else 0, 1)
+    pad = np.zeros((n, k), np.int64)
     for i, ix in enumerate(idx_lists):
         pad[i, :len(ix)] = ix
-    q = (points[pad] - centers[:, None, :]) * mask[:, :, None]
-    c = np.maximum(cnt, 1)[:, None]
-    m = q.sum(1) / c
-    covs = np.einsum("nki,nkj->nij", q, q) / c[:, :, None] - m[:, :, None] * m[:, None, :]
-    normals = np.tile(np.array([0.0, 0.0, 1.0]), (n, 1))
-    ok = cnt >= 3
-    if ok.any():
-        _, v = np.linalg.eigh(covs[ok])
-        v0 = v[:, :, 0]
-        a = np.abs(v0)
-        lead = np.where((a[:, 0] >= a[:, 1]) & (a[:, 0] >= a[:, 2]), v0[:, 0], np.where(a[:, 1] >= a[:, 2], v0[:, 1], v0[:, 2]))
-        normals[ok] = np.where((lead < 0)[:, None], -v0, v0)
+    pts = np.ascontiguousarray(points, np.float64)
+    cov = np.empty((n, 3, 3))
+    c = None if cfg is None else np.ascontiguousarray(cfg, np.int32)
+    L.r3d_oracle_cumulant_cov(pts.ctypes.data_as(dp), pad.ctypes.data_as(i64p), cnt.ctypes.data_as(i32p), n, k,
+                              None if c is None else c.ctypes.data_as(i32p), cov.ctypes.data_as(dp))
+    return cov, cnt
+
+
+def fast_eigen3x3(covs, cfg=None):
+    """FastEigen3x3 of every covariance (oracle/normals.c): eigenvector of the smallest eigenvalue with the sign the closed
+    form produces; the zero vector for an all-zero matrix."""
+    L, dp, _, i32p = _normals_lib()
+    covs = np.ascontiguousarray(covs, np.float64).reshape(-1, 9)
+    out = np.empty((len(covs), 3))
+    c = None if cfg is None else np.ascontiguousarray(cfg, np.int32)
+    L.r3d_oracle_fast_eigen3x3(covs.ctypes.data_as(dp), len(covs), None if c is None else c.ctypes.data_as(i32p), out.ctypes.data_as(dp))
+    return out
+
+
+def _pca_normals(points, idx_lists, prev_normals=None, centers=None, cfg=None):
+    """Legacy PointCloud::EstimateNormals on given neighbour lists (nearest first): cumulant covariance -> FastEigen3x3
+    (oracle/normals.c, PINNED by the recorded frames sign included); fewer than 3 neighbours (identity covariance) or an all-zero
+    covariance -> (0,0,1) (the previous normal if the cloud has normals); a cloud that already carries normals keeps their
+    orientation (each new normal is turned towards the old one).  `centers` is accepted for the callers that restrict the
+    queries to a subset; the covariance itself only depends on the neighbour lists.  Returns (normals, covariances)."""
+    covs, cnt = cumulant_covariances(points, idx_lists, cfg)
+    normals = fast_eigen3x3(covs, cfg)
+    zero = (normals == 0).all(1)
     if prev_normals is not None:
-        flip = (normals * prev_normals).sum(1) < 0
+        prev = np.asarray(prev_normals, float)
+        normals[zero] = prev[zero]
+        flip = (normals * prev).sum(1) < 0
         normals[flip] = -normals[flip]
+    else:
+        normals[zero] = (0.0, 0.0, 1.0)
     return normals, covs
 
 
@@ -477,7 +507,7 @@ def registration(source, target, max_dist, init=None, mode="p2p", max_iteration=
 
 
 # -------------------------------------------------------------------------------------------- scanning loops
-def fuse_loop(frames, flavour="icp", threshold=0.02, voxel_size=0.01, max_iter=100, log=None):
+def fuse_loop(frames, flavour="icp", threshold=0.02, voxel_size=0.01, max_iter=100, log=None, hook=None):
     """The reference's scanning loops on a list of frames (None / empty = failed capture, skipped: main.py:39,53-54).
     flavour "icp"  -- main.py:34-54 with pointcloud_alignment.py:6-43: the first valid frame becomes the model; every later
         frame: voxel_down_sample(voxel_size) of frame AND model, registration_icp(PointToPoint, threshold, identity,
@@ -486,8 +516,11 @@ def fuse_loop(frames, flavour="icp", threshold=0.02, voxel_size=0.01, max_iter=1
         (threshold, identity, default criteria = 30 iterations) of the frame against the whole model, points and normals
         transformed and appended, then estimate_normals(Hybrid(0.05, 30)) on the whole model (:148), which keeps the
         orientation of the normals already there.
-    Returns (model points, model normals or None); `log` (list) receives one registration result per aligned frame."""
+    Returns (model points, model normals or None); `log` (list) receives one registration result per aligned frame.
+    `hook(k, T)` (sensitivity experiments only, tools/cpu_gicp_sensitivity.py) may return a replacement for the k-th
+    registration's transform before it is applied."""
     model = model_n = None
+    k = 0
     for f in frames:
         if f is None:
             continue
@@ -506,9 +539,13 @@ def fuse_loop(frames, flavour="icp", threshold=0.02, voxel_size=0.01, max_iter=1
             res = registration(fp, model, threshold, mode="gicp", max_iteration=30, target_normals=model_n,
                                target_cov=covariances_from_normals(model_n), source_cov=covariances_from_normals(fn))
             T = res["T"]
+            if hook is not None:
+                T2 = hook(k, T)
+                T = T if T2 is None else T2
             model = np.concatenate([model, transform_points(T, fp)], 0)
             model_n = np.concatenate([model_n, transform_points(T, fn, rotate_only=True)], 0)
             model_n = estimate_normals_hybrid(model, 0.05, 30, prev_normals=model_n)
+        k += 1
         if log is not None:
             log.append(res)
     return model, model_n

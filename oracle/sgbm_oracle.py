@@ -20,7 +20,7 @@ class SgbmParams(ctypes.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("sgbm3way.c", "graph.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("sgbm3way.c", "graph.c", "normals.c", "Makefile")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
     return _SO
