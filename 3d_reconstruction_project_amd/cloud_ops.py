@@ -30,6 +30,23 @@ _lib.register({
 
 P2P, P2PLANE, GICP = 0, 1, 2
 
+_lib.register({
+    "r3d_debug_sort_by_cell": ([_vp, _vp, ctypes.c_int64, _vp, ctypes.c_double, _vp, ctypes.c_int32, ctypes.c_int32, _vp, _vp], ctypes.c_int),
+})
+
+
+def debug_sort_by_cell(points, origin, cell, dims, key_order, impl=0, ctx=None):
+    """r3d_debug_sort_by_cell: (idx, keys) of the stable (cell key, index) sort; impl 0 = counting sort, 1 = radix fallback."""
+    ctx = ctx or _lib.default_context()
+    p = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    org = np.ascontiguousarray(origin, dtype=np.float64)
+    d = np.ascontiguousarray(dims, dtype=np.int32)
+    idx = np.empty(len(p), np.int32)
+    keys = np.empty(len(p), np.uint64)
+    ctx.call("r3d_debug_sort_by_cell", p.ctypes.data_as(_vp), len(p), org.ctypes.data_as(_vp), float(cell), d.ctypes.data_as(_vp), int(key_order),
+             int(impl), idx.ctypes.data_as(_vp), keys.ctypes.data_as(_vp))
+    return idx, keys
+
 
 class AlignParams(ctypes.Structure):
     _fields_ = [("icp", _lib.IcpParams), ("voxel_size", ctypes.c_double), ("normal_radius", ctypes.c_double),

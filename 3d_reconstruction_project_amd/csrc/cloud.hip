@@ -129,6 +129,258 @@ __global__ void __launch_bounds__(256) k_gather3(const double *__restrict__ src,
     dst[i * 3] = src[(int64_t)j * 3]; dst[i * 3 + 1] = src[(int64_t)j * 3 + 1]; dst[i * 3 + 2] = src[(int64_t)j * 3 + 2];
 }
 
+// ================================================================================== hand-written exclusive scan (int32 / packed 64)
+// Reduce-then-scan in two launches: k_scan_sums leaves one sum per 4096-element tile; k_scan_apply first adds up the tile sums in
+// front of its own tile (the list is short: 2 000 tiles for an 8 MP image, read from L2) and then scans its tile.  Integer adds:
+// the result does not depend on the order, so it is deterministic.  T = int (flags, cell populations) or unsigned long long
+// (two counters packed: points in the low word, runs in the high word; both stay below 2^31 so no carry crosses).
+constexpr int SCAN_T = 256, SCAN_I = 16, SCAN_TILE = SCAN_T * SCAN_I;
+template <class T>
+__device__ __forceinline__ T wave_incl_scan(T v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const T t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+// one value per thread of a 256-thread workgroup -> exclusive prefix; *total = workgroup sum
+template <class T>
+__device__ __forceinline__ T block_excl_scan(T v, T *total, T *ws /* 4 entries of LDS */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const T incl = wave_incl_scan<T>(v, lane);
+    if (lane == 63) ws[w] = incl;
+    __syncthreads();
+    T off = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { if (i < w) off += ws[i]; tot += ws[i]; }
+    __syncthreads();
+    *total = tot;
+    return off + incl - v;
+}
+// 16 consecutive elements of a thread as 16-byte accesses when the whole group is inside the array (the arrays come from the arena:
+// 256-byte aligned, and base is a multiple of 16 elements)
+template <class T>
+__device__ __forceinline__ void scan_load16(const T *__restrict__ in, int64_t base, int64_t n, T v[SCAN_I]) {
+    if (base + SCAN_I <= n) {
+        constexpr int PER = 16 / sizeof(T);
+        typedef T vec_t __attribute__((ext_vector_type(PER)));
+        const vec_t *p = reinterpret_cast<const vec_t *>(in + base);
+#pragma unroll
+        for (int q = 0; q < SCAN_I / PER; q++) {
+            const vec_t t = p[q];
+#pragma unroll
+            for (int c = 0; c < PER; c++) v[q * PER + c] = t[c];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_I; j++) v[j] = base + j < n ? in[base + j] : (T)0;
+    }
+}
+template <class T>
+__global__ void __launch_bounds__(SCAN_T) k_scan_sums(const T *__restrict__ in, int64_t n, T *__restrict__ part) {
+    __shared__ T ws[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_I;
+    T v[SCAN_I], s = 0;
+    scan_load16<T>(in, base, n, v);
+#pragma unroll
+    for (int j = 0; j < SCAN_I; j++) s += v[j];
+    T tot;
+    (void)block_excl_scan<T>(s, &tot, ws);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+// hi_max (T = unsigned long long only): the largest HIGH word of any input element (runs per bucket), by atomicMax
+template <class T>
+__global__ void __launch_bounds__(SCAN_T) k_scan_apply(const T *__restrict__ in, int64_t n, const T *__restrict__ part, T *__restrict__ out,
+                                                       int *__restrict__ lo_out, int *__restrict__ hi_max) {
+    __shared__ T ws[4];
+    T acc = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_T) acc += part[b];
+    T tile_off;
+    (void)block_excl_scan<T>(acc, &tile_off, ws);
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_I;
+    T v[SCAN_I], s = 0;
+    int hm = 0;
+    scan_load16<T>(in, base, n, v);
+#pragma unroll
+    for (int j = 0; j < SCAN_I; j++) {
+        if (sizeof(T) == 8) hm = max(hm, (int)((unsigned long long)v[j] >> 32));
+        s += v[j];
+    }
+    T tot;
+    T run = tile_off + block_excl_scan<T>(s, &tot, ws);
+    if (base + SCAN_I <= n && !lo_out) {
+        constexpr int PER = 16 / sizeof(T);
+        typedef T vec_t __attribute__((ext_vector_type(PER)));
+        vec_t *p = reinterpret_cast<vec_t *>(out + base);
+#pragma unroll
+        for (int q = 0; q < SCAN_I / PER; q++) {
+            vec_t t;
+#pragma unroll
+            for (int c = 0; c < PER; c++) { t[c] = run; run += v[q * PER + c]; }
+            p[q] = t;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_I; j++) {
+            if (base + j < n) {
+                out[base + j] = run;
+                if (lo_out) lo_out[base + j] = (int)(unsigned)run;
+            }
+            run += v[j];
+        }
+    }
+    if (sizeof(T) == 8 && hi_max) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) hm = max(hm, __shfl_xor(hm, o));
+        if ((threadIdx.x & 63) == 0 && hm > 0) atomicMax(hi_max, hm);
+    }
+}
+
+// ================================================================================== stable counting sort by cell key, run based
+// Sorts point indices by (key, index) WITHOUT a radix pass.  Consecutive points with the same key (the pixels of an image row that
+// fall into one voxel; the members of a voxelised cloud in key order) form a RUN; a run is one record (key, first index,
+// length).  k_cs_runs detects runs inside every wave (64 consecutive points), counts per BUCKET -- a coarse prefix of the key: the
+// (kx, ky) column of a z-fastest voxel key, the high bits of a Morton or x-fastest key -- how many runs and points it receives
+// (one 64-bit atomic per run head: runs << 32 | points) and hands every run a slot in a global list.  After a scan of the bucket
+// table, k_cs_place files every run under its bucket, k_cs_rank gives every run its final position by counting, among the runs
+// of ITS bucket, the points of those that sort before it by (key, first index) -- the only quadratic step, in runs per bucket
+// (tens) -- and k_cs_emit writes every point to final base + offset inside its run.  Arrival order (the atomics) only picks
+// scratch slots: the result is the unique stable order, identical to a stable radix sort.  The bucket table is small (L2
+// resident); the point arrays are read and written once each.
+template <class KEY>
+struct CsRun { KEY key; int start, len; unsigned bucket; int gid; };
+struct CsGeom { double ox, oy, oz, cell; int nx, ny, nz, key_order, shift; unsigned long long div; };   // bucket = key >> shift, or key / div when shift < 0
+
+template <class KEY>
+__device__ __forceinline__ void cs_key(const double *__restrict__ p, int64_t i, const CsGeom &g, KEY &full, unsigned &bucket) {
+    int cx, cy, cz;
+    if (g.key_order == 1) {  // voxel keys: the legacy index is floor((p - origin) / voxel) with a true division
+        cx = (int)floor((p[i * 3] - g.ox) / g.cell); cy = (int)floor((p[i * 3 + 1] - g.oy) / g.cell); cz = (int)floor((p[i * 3 + 2] - g.oz) / g.cell);
+    } else if (g.key_order == 3) {  // tensor voxel keys: floor(float(p) / float(voxel)) in float32, grid origin 0; ox..oz = smallest key
+        const float v = (float)g.cell;
+        cx = (int)((long long)floorf((float)p[i * 3] / v) - (long long)g.ox);
+        cy = (int)((long long)floorf((float)p[i * 3 + 1] / v) - (long long)g.oy);
+        cz = (int)((long long)floorf((float)p[i * 3 + 2] / v) - (long long)g.oz);
+    } else {               // search grid: must agree with cell_coord() used by the queries
+        const double inv = 1.0 / g.cell;
+        cx = cell_coord(p[i * 3], g.ox, inv); cy = cell_coord(p[i * 3 + 1], g.oy, inv); cz = cell_coord(p[i * 3 + 2], g.oz, inv);
+    }
+    cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1); cz = min(max(cz, 0), g.nz - 1);
+    unsigned long long k;
+    if (g.key_order == 2) {
+        auto spread = [](unsigned long long v) {  // 21 bits -> every third bit
+            v &= 0x1fffffull;
+            v = (v | v << 32) & 0x1f00000000ffffull;
+            v = (v | v << 16) & 0x1f0000ff0000ffull;
+            v = (v | v << 8) & 0x100f00f00f00f00full;
+            v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+            v = (v | v << 2) & 0x1249249249249249ull;
+            return v;
+        };
+        k = spread((unsigned long long)cx) | spread((unsigned long long)cy) << 1 | spread((unsigned long long)cz) << 2;
+        bucket = (unsigned)(k >> g.shift);
+    } else if (g.key_order == 0) {
+        k = ((unsigned long long)cz * g.ny + cy) * g.nx + cx;
+        bucket = (unsigned)(k >> g.shift);
+    } else {   // 1 and 3: z fastest; bucket = a stretch of g.div consecutive keys (a piece of a (kx, ky) column)
+        k = ((unsigned long long)cx * g.ny + cy) * g.nz + cz;
+        bucket = sizeof(KEY) == 4 ? (unsigned)k / (unsigned)g.div : (unsigned)(k / g.div);
+    }
+    full = (KEY)k;
+}
+
+template <class KEY>
+__global__ void __launch_bounds__(256) k_cs_runs(const double *__restrict__ p, int64_t n, CsGeom g, KEY *__restrict__ keys, int *__restrict__ gid_of,
+                                                 unsigned long long *__restrict__ cnt, CsRun<KEY> *__restrict__ runs) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < n;
+    KEY key = 0;
+    unsigned bucket = 0;
+    if (valid) cs_key<KEY>(p, i, g, key, bucket);
+    const KEY prev = __shfl_up(key, 1);
+    const bool head = valid && (lane == 0 || prev != key);
+    const unsigned long long hm = __ballot(head), vm = __ballot(valid);
+    if (vm == 0) return;
+    const unsigned long long upto = (2ull << lane) - 1ull;           // bits 0 .. lane (lane 63: all ones)
+    const int hp = 63 - __clzll((long long)(hm & upto));              // lane of my run's head (lane 0 is always a head)
+    const unsigned long long above = hm & ~upto;
+    const int nxt = above ? __ffsll((long long)above) - 1 : __popcll(vm);   // valid lanes are a prefix of the wave
+    // a run is named by the index of its first point (no global counter: one address hit by every wave of the grid serialises)
+    if (head) {
+        const int len = nxt - lane;
+        const unsigned long long old = atomicAdd(&cnt[bucket], (1ull << 32) | (unsigned long long)len);
+        CsRun<KEY> r;
+        r.key = key; r.start = (int)i; r.len = len; r.bucket = bucket;
+        r.gid = (int)(old >> 32);      // arrival number of the run inside its bucket (picks a scratch slot only) until k_cs_place
+        runs[i] = r;
+    }
+    if (valid) { keys[i] = key; gid_of[i] = (int)i - (lane - hp); }
+}
+// files every run under its bucket: placed[run_start(bucket) + arrival number]; one thread per point, run heads act
+template <class KEY>
+__global__ void __launch_bounds__(256) k_cs_place(const CsRun<KEY> *__restrict__ runs, const int *__restrict__ gid_of, int64_t n,
+                                                  const unsigned long long *__restrict__ start, CsRun<KEY> *__restrict__ placed) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || gid_of[i] != (int)i) return;
+    CsRun<KEY> r = runs[i];
+    const int slot = (int)(start[r.bucket] >> 32) + r.gid;
+    r.gid = (int)i;
+    placed[slot] = r;
+}
+// final position of every run: points of its bucket's runs that sort before it by (key, first index).  Wave-cooperative: the 64
+// runs of a wave lie in consecutive buckets, so the union of their buckets' run lists is ONE contiguous stretch of `placed`; the
+// wave reads it 64 records at a time (one coalesced load) and every lane tests all 64 through v_readlane (uniform index), counting
+// only the records of its own bucket.  Cost per wave: union length x ~8 instructions, whatever the split into buckets.
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, l), hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return (unsigned long long)hi << 32 | lo;
+}
+template <class KEY>
+__global__ void __launch_bounds__(256) k_cs_rank(const CsRun<KEY> *__restrict__ placed, int nruns, const unsigned long long *__restrict__ start,
+                                                 int *__restrict__ final_base) {
+    const int s = blockIdx.x * 256 + threadIdx.x;   // nruns = high word of the scan total, read by the host together with the fallback test
+    if ((s & ~63) >= nruns) return;                  // whole wave beyond the list
+    const bool valid = s < nruns;
+    const CsRun<KEY> me = placed[valid ? s : nruns - 1];
+    const unsigned long long b0 = start[me.bucket], b1 = start[me.bucket + 1];
+    const int rb = (int)(b0 >> 32), re = (int)(b1 >> 32);
+    int acc = (int)(unsigned)b0;
+    const int u0 = __builtin_amdgcn_readfirstlane(rb);
+    int u1 = re;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) u1 = max(u1, __shfl_xor(u1, o));
+    u1 = __builtin_amdgcn_readfirstlane(u1);
+    const int lane = threadIdx.x & 63;
+    for (int c = u0; c < u1; c += 64) {
+        const CsRun<KEY> o = placed[min(c + lane, nruns - 1)];
+        const int lim = min(64, u1 - c);
+        for (int t = 0; t < lim; t++) {
+            KEY ok;
+            if (sizeof(KEY) == 8) ok = (KEY)readlane_u64((unsigned long long)o.key, t);
+            else ok = (KEY)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)o.key, t);
+            const int os = __builtin_amdgcn_readlane(o.start, t), ol = __builtin_amdgcn_readlane(o.len, t);
+            const int j = c + t;
+            const bool less = ok < me.key || (ok == me.key && os < me.start);
+            acc += (j >= rb && j < re && less) ? ol : 0;
+        }
+    }
+    if (valid) final_base[me.gid] = acc;
+}
+// every point to its final slot; optionally the gathered coordinates as well (the cell-sorted copy a search grid needs)
+template <class KEY>
+__global__ void __launch_bounds__(256) k_cs_emit(const KEY *__restrict__ keys, const int *__restrict__ gid_of, const int *__restrict__ final_base, int64_t n, KEY *__restrict__ keys_out, int *__restrict__ idx_out,
+                                                 const double *__restrict__ pts, double *__restrict__ sorted) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int g = gid_of[i];                                         // = index of the first point of my run
+    const int64_t o = (int64_t)final_base[g] + ((int)i - g);
+    keys_out[o] = keys[i];
+    idx_out[o] = (int)i;
+    if (sorted) { sorted[o * 3] = pts[i * 3]; sorted[o * 3 + 1] = pts[i * 3 + 1]; sorted[o * 3 + 2] = pts[i * 3 + 2]; }
+}
+
 // ------------------------------------------------------------------------------------------------ voxel
 // segment heads of the sorted key array -> compact list of segment starts (one output voxel per segment)
 template <class KEY>
@@ -142,54 +394,106 @@ __global__ void __launch_bounds__(256) k_seg_starts(const int *__restrict__ flag
     if (i >= n) return;
     if (flags[i]) starts[scan[i]] = (int)i;
 }
-// one thread per voxel: sequential float64 sums in ORIGINAL point order (stable sort), exactly like the
-// accumulate-then-divide of the legacy VoxelDownSample
-__global__ void __launch_bounds__(256) k_voxel_mean(const double *__restrict__ a, const int *__restrict__ idx, const int *__restrict__ starts,
-                                                    int64_t nseg, int64_t n, double *__restrict__ out) {
-    int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (s >= nseg) return;
-    int b = starts[s], e = s + 1 < nseg ? starts[s + 1] : (int)n;
-    double x = 0, y = 0, z = 0;
-    // eight members per round trip: indices first, then all eight gathers, then the additions in their original order (a
-    // member at a time costs two dependent round trips each, and a wave waits for its most populated voxel: 1.02 ms for the
-    // 7.6 M points of an 8 MP view, a fifth of the GPU time of the whole view chain)
+// Voxel means: sequential sums in ORIGINAL point order (the sort is stable), exactly like the accumulate-then-divide of the legacy
+// VoxelDownSample (T = double) / of the tensor method (T = float: members rounded to float32, float32 sums, float32 count).
+// One thread per voxel keeps the order, and the kernel then lasts as long as its most populated voxel's chain of round trips
+// (1 400 members in the near field of an 8 MP view: 175 rounds of 8, 0.30 ms for a kernel that moves 0.2 GB).  So voxels with more
+// than VM_BIG members are only LISTED by k_voxel_mean_t (one wave-aggregated atomic per wave) and summed by k_voxel_mean_big, a wave
+// per voxel: 64 members per round trip (coalesced index read, 64 gathers in flight), added in order through v_readlane -- every
+// lane carries the same running sum, the additions are the voxel's own sequential chain, nothing else waits on them.
+// (A form that staged 64 voxels' members through LDS windows was measured 3x SLOWER: where voxels are larger than the window only
+// one lane walks at a time; 16 members per thread and round trip instead of 8: 2x slower.)
+constexpr int VM_BIG = 192;
+template <class T>
+__global__ void __launch_bounds__(256) k_voxel_mean_t(const double *__restrict__ a, const int *__restrict__ idx, const int *__restrict__ starts,
+                                                      int64_t nseg, int64_t n, double *__restrict__ out, int *__restrict__ big_list,
+                                                      int *__restrict__ big_count) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = s < nseg;
+    const int b = live ? starts[s] : 0, e = live ? (s + 1 < nseg ? starts[s + 1] : (int)n) : 0;
+    const bool big = e - b > VM_BIG;
+    const unsigned long long bm = __ballot(big);
+    if (bm) {   // wave-uniform
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(big_count, __popcll(bm));
+        base = __shfl(base, 0);
+        if (big) big_list[base + __popcll(bm & ((1ull << lane) - 1ull))] = (int)s;
+    }
+    if (!live || big) return;
+    T x = 0, y = 0, z = 0;
     for (int i0 = b; i0 < e; i0 += 8) {
         int64_t j[8];
-        double X[8], Y[8], Z[8];
+        T X[8], Y[8], Z[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) j[u] = idx[min(i0 + u, e - 1)];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { X[u] = a[j[u] * 3]; Y[u] = a[j[u] * 3 + 1]; Z[u] = a[j[u] * 3 + 2]; }
+        for (int u = 0; u < 8; u++) { X[u] = (T)a[j[u] * 3]; Y[u] = (T)a[j[u] * 3 + 1]; Z[u] = (T)a[j[u] * 3 + 2]; }
 #pragma unroll
         for (int u = 0; u < 8; u++)
             if (i0 + u < e) { x += X[u]; y += Y[u]; z += Z[u]; }
     }
-    double c = (double)(e - b);
-    out[s * 3] = x / c; out[s * 3 + 1] = y / c; out[s * 3 + 2] = z / c;
-}
-
-// tensor (o3d.t) voxel_down_sample: members rounded to float32, summed in float32 in original order, divided by a float32 count
-__global__ void __launch_bounds__(256) k_voxel_mean_f32(const double *__restrict__ a, const int *__restrict__ idx, const int *__restrict__ starts,
-                                                        int64_t nseg, int64_t n, double *__restrict__ out) {
-    int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (s >= nseg) return;
-    int b = starts[s], e = s + 1 < nseg ? starts[s + 1] : (int)n;
-    float x = 0, y = 0, z = 0;
-    for (int i0 = b; i0 < e; i0 += 8) {
-        int64_t j[8];
-        float X[8], Y[8], Z[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) j[u] = idx[min(i0 + u, e - 1)];
-#pragma unroll
-        for (int u = 0; u < 8; u++) { X[u] = (float)a[j[u] * 3]; Y[u] = (float)a[j[u] * 3 + 1]; Z[u] = (float)a[j[u] * 3 + 2]; }
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-            if (i0 + u < e) { x += X[u]; y += Y[u]; z += Z[u]; }
-    }
-    const float c = (float)(e - b);
+    const T c = (T)(e - b);
     out[s * 3] = (double)(x / c); out[s * 3 + 1] = (double)(y / c); out[s * 3 + 2] = (double)(z / c);
 }
-
+// the same sums over the points IN SORTED ORDER (the sort wrote them, k_cs_emit): a voxel's members are one contiguous stretch, so
+// a lane streams whole cache lines instead of gathering 24 bytes from each; the next eight members are requested before the
+// current eight are added
+template <class T>
+__global__ void __launch_bounds__(256) k_voxel_mean_sorted(const double *__restrict__ sp, const int *__restrict__ starts, int64_t nseg, int64_t n,
+                                                           double *__restrict__ out) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= nseg) return;
+    const int b = starts[s], e = s + 1 < nseg ? starts[s + 1] : (int)n, m = e - b;
+    const double *__restrict__ p = sp + (int64_t)b * 3;
+    T x = 0, y = 0, z = 0;
+    double cur[24], nxt[24];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int64_t q = (int64_t)min(u, m - 1) * 3;
+        cur[u * 3] = p[q]; cur[u * 3 + 1] = p[q + 1]; cur[u * 3 + 2] = p[q + 2];
+    }
+    for (int i0 = 0; i0 < m; i0 += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int64_t q = (int64_t)min(i0 + 8 + u, m - 1) * 3;
+            nxt[u * 3] = p[q]; nxt[u * 3 + 1] = p[q + 1]; nxt[u * 3 + 2] = p[q + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i0 + u < m) { x += (T)cur[u * 3]; y += (T)cur[u * 3 + 1]; z += (T)cur[u * 3 + 2]; }
+#pragma unroll
+        for (int u = 0; u < 24; u++) cur[u] = nxt[u];
+    }
+    const T c = (T)m;
+    out[s * 3] = (double)(x / c); out[s * 3 + 1] = (double)(y / c); out[s * 3 + 2] = (double)(z / c);
+}
+__device__ __forceinline__ double readlane_t(double v, int l) { return __longlong_as_double((long long)readlane_u64((unsigned long long)__double_as_longlong(v), l)); }
+__device__ __forceinline__ float readlane_t(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+template <class T>
+__global__ void __launch_bounds__(64) k_voxel_mean_big(const double *__restrict__ a, const int *__restrict__ idx, const int *__restrict__ starts,
+                                                       int64_t nseg, int64_t n, double *__restrict__ out, const int *__restrict__ big_list,
+                                                       const int *__restrict__ big_count) {
+    const int lane = threadIdx.x, nbig = *big_count;
+    for (int q = blockIdx.x; q < nbig; q += gridDim.x) {
+        const int64_t s = big_list[q];
+        const int b = starts[s], e = s + 1 < nseg ? starts[s + 1] : (int)n;
+        T x = 0, y = 0, z = 0;
+        int64_t j = idx[min(b + lane, e - 1)];
+        T X = (T)a[j * 3], Y = (T)a[j * 3 + 1], Z = (T)a[j * 3 + 2];
+        for (int c = b; c < e; c += 64) {
+            const int64_t jn = idx[min(c + 64 + lane, e - 1)];                      // next chunk in flight while this one is added
+            const T Xn = (T)a[jn * 3], Yn = (T)a[jn * 3 + 1], Zn = (T)a[jn * 3 + 2];
+            const int lim = min(64, e - c);
+            for (int t = 0; t < lim; t++) { x += readlane_t(X, t); y += readlane_t(Y, t); z += readlane_t(Z, t); }
+            X = Xn; Y = Yn; Z = Zn;
+        }
+        if (lane == 0) {
+            const T cnt = (T)(e - b);
+            out[s * 3] = (double)(x / cnt); out[s * 3 + 1] = (double)(y / cnt); out[s * 3 + 2] = (double)(z / cnt);
+        }
+    }
+}
 // ------------------------------------------------------------------------------------------------ search
 // visits the cells of Chebyshev shell s around (cx,cy,cz); F(slot_begin, slot_end) is called per non-empty cell
 template <class F>
@@ -1328,6 +1632,73 @@ struct DevArena {  // simple bump allocator over ctx->cloud_bufs (grow-only, reu
     }
 };
 
+// Small device -> host reads between kernels (counts, bounding boxes): every piece lands in the context's PINNED buffer with an
+// asynchronous copy and ONE stream synchronise follows.  (A hipMemcpyAsync into pageable memory is staged and waited for piece by
+// piece: two 4-byte reads cost two host round trips of ~20 us each on this box, the kernel trace shows them as separate gaps.)
+struct PinRead {
+    r3d_ctx *ctx;
+    size_t off = 0;
+    struct Piece { void *host; size_t off, bytes; } piece[8];
+    int n = 0;
+    explicit PinRead(r3d_ctx *c) : ctx(c) {}
+    int add(void *host, const void *dev, size_t bytes) {
+        if (!ctx->pin) {
+            hipError_t e = hipHostMalloc(&ctx->pin, R3D_PIN_BYTES);
+            if (e != hipSuccess) { ctx->pin = nullptr; return r3d_fail(ctx, R3D_E_OOM, "hipHostMalloc(%d) failed: %s", R3D_PIN_BYTES, hipGetErrorString(e)); }
+        }
+        if (n >= 8 || off + bytes > R3D_PIN_BYTES) return r3d_fail(ctx, R3D_E_HIP, "PinRead: too much for one read-back");
+        R3D_HIP(ctx, hipMemcpyAsync((char *)ctx->pin + off, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        piece[n++] = Piece{host, off, bytes};
+        off += (bytes + 15) & ~(size_t)15;
+        return R3D_OK;
+    }
+    int wait() {
+        // a blocking stream synchronise may put the thread to sleep for a scheduler tick (the kernel trace showed ~40 us between the
+        // copy and the next launch); the reads are a few microseconds away, so poll an event briefly first, then wait properly
+        if (!ctx->pin_ev) R3D_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_ev, hipEventDisableTiming));
+        R3D_HIP(ctx, hipEventRecord(ctx->pin_ev, ctx->stream));
+        bool done = false;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; !done; spins++) {
+            const hipError_t q = hipEventQuery(ctx->pin_ev);
+            if (q == hipSuccess) { done = true; break; }
+            if (q != hipErrorNotReady) return r3d_fail(ctx, R3D_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+            if ((spins & 15) == 15 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 3e-4) break;
+        }
+        if (!done) R3D_HIP(ctx, hipEventSynchronize(ctx->pin_ev));
+        for (int i = 0; i < n; i++) memcpy(piece[i].host, (const char *)ctx->pin + piece[i].off, piece[i].bytes);
+        n = 0;
+        off = 0;
+        return R3D_OK;
+    }
+};
+
+// big_ws: >= (nseg + 16) ints of scratch (the counter, then the list)
+static inline int launch_voxel_mean(r3d_ctx *ctx, DevArena &ar, bool f32, const double *a, const int *idx, const int *starts, int64_t nseg, int64_t n,
+                                    double *out, const double *sorted = nullptr) {
+    if (sorted) {   // `a` in sorted order is available (the sort wrote it): contiguous streams, no index list
+        const unsigned nbs = (unsigned)((nseg + 255) / 256);
+        if (f32) k_voxel_mean_sorted<float><<<nbs, 256, 0, ctx->stream>>>(sorted, starts, nseg, n, out);
+        else k_voxel_mean_sorted<double><<<nbs, 256, 0, ctx->stream>>>(sorted, starts, nseg, n, out);
+        R3D_HIP(ctx, hipGetLastError());
+        return R3D_OK;
+    }
+    int *ws = (int *)ar.get((size_t)(nseg + 16) * 4);
+    if (ar.rc) return ar.rc;
+    R3D_HIP(ctx, hipMemsetAsync(ws, 0, 64, ctx->stream));
+    const unsigned nb = (unsigned)((nseg + 255) / 256);
+    const unsigned nbig = (unsigned)std::min<int64_t>(nseg, 4096);
+    if (f32) {
+        k_voxel_mean_t<float><<<nb, 256, 0, ctx->stream>>>(a, idx, starts, nseg, n, out, ws + 16, ws);
+        k_voxel_mean_big<float><<<nbig, 64, 0, ctx->stream>>>(a, idx, starts, nseg, n, out, ws + 16, ws);
+    } else {
+        k_voxel_mean_t<double><<<nb, 256, 0, ctx->stream>>>(a, idx, starts, nseg, n, out, ws + 16, ws);
+        k_voxel_mean_big<double><<<nbig, 64, 0, ctx->stream>>>(a, idx, starts, nseg, n, out, ws + 16, ws);
+    }
+    R3D_HIP(ctx, hipGetLastError());
+    return R3D_OK;
+}
+
 struct Grid {
     GridView v;
     int64_t n = 0;
@@ -1344,8 +1715,11 @@ int cloud_bbox(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, doubl
     k_bbox_partial<<<nb, 256, 0, ctx->stream>>>(d_pts, n, part);
     R3D_HIP(ctx, hipGetLastError());
     std::vector<double> h((size_t)nb * 6);
-    R3D_HIP(ctx, hipMemcpyAsync(h.data(), part, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        PinRead rd(ctx);
+        int prc;
+        if ((prc = rd.add(h.data(), part, h.size() * 8)) || (prc = rd.wait())) return prc;
+    }
     for (int a = 0; a < 3; a++) { mn[a] = 1e300; mx[a] = -1e300; }
     for (int b = 0; b < nb; b++)
         for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], h[(size_t)b * 6 + a]); mx[a] = std::max(mx[a], h[(size_t)b * 6 + 3 + a]); }
@@ -1357,11 +1731,23 @@ int cloud_bbox(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, doubl
     return R3D_OK;
 }
 
-// sorts point indices by cell key; fills keys_sorted / idx_sorted (device).  The keys are 32-bit whenever the key space allows
-// (the radix passes then move half the bytes); *keys32 tells the caller which type keys_sorted points to.
+// exclusive scan of n ints / packed 64-bit counters on the ctx stream (k_scan_sums + k_scan_apply)
+template <class T>
+int dev_exclusive_scan(r3d_ctx *ctx, DevArena &ar, const T *in, T *out, int64_t n, int *lo_out = nullptr, int *hi_max = nullptr) {
+    if (n <= 0) return R3D_OK;
+    const int tiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+    T *part = (T *)ar.get((size_t)tiles * sizeof(T));
+    if (ar.rc) return ar.rc;
+    k_scan_sums<T><<<tiles, SCAN_T, 0, ctx->stream>>>(in, n, part);
+    k_scan_apply<T><<<tiles, SCAN_T, 0, ctx->stream>>>(in, n, part, out, lo_out, hi_max);
+    R3D_HIP(ctx, hipGetLastError());
+    return R3D_OK;
+}
+
+// the library radix sort: only for key spaces / bucket populations the counting sort below declines (R3D_SORT_IMPL=radix forces it)
 template <class KEY>
-int sort_by_cell_t(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, const double org[3], double cell, const int dims[3],
-                   int key_order, int bits, void **keys_sorted, int **idx_sorted) {
+int radix_sort_by_cell_t(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, const double org[3], double cell, const int dims[3],
+                         int key_order, int bits, void **keys_sorted, int **idx_sorted) {
     KEY *k0 = (KEY *)ar.get((size_t)n * sizeof(KEY)), *k1 = (KEY *)ar.get((size_t)n * sizeof(KEY));
     int *v0 = (int *)ar.get((size_t)n * 4), *v1 = (int *)ar.get((size_t)n * 4);
     if (ar.rc) return ar.rc;
@@ -1377,8 +1763,55 @@ int sort_by_cell_t(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, c
     *idx_sorted = v1;
     return R3D_OK;
 }
+
+constexpr int CS_MAX_RUNS = 4096;          // runs per bucket above which k_cs_rank's quadratic step is declined (radix fallback)
+constexpr int64_t CS_MAX_BUCKETS = 1ll << 26;
+// returns R3D_OK with *done = false when it declines (more than CS_MAX_RUNS runs in one bucket)
+template <class KEY>
+int counting_sort_by_cell_t(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, const CsGeom &g, int64_t nbuckets, void **keys_sorted,
+                            int **idx_sorted, double *sorted_pts, bool *done) {
+    *done = false;
+    KEY *keys = (KEY *)ar.get((size_t)n * sizeof(KEY)), *keys_out = (KEY *)ar.get((size_t)n * sizeof(KEY));
+    int *gid_of = (int *)ar.get((size_t)n * 4), *idx_out = (int *)ar.get((size_t)n * 4), *final_base = (int *)ar.get((size_t)n * 4);
+    CsRun<KEY> *runs = (CsRun<KEY> *)ar.get((size_t)n * sizeof(CsRun<KEY>)), *placed = (CsRun<KEY> *)ar.get((size_t)n * sizeof(CsRun<KEY>));
+    // bucket table (nbuckets + 1 entries, the last one stays 0) followed by the counter cell: ONE fill zeroes both
+    unsigned long long *cnt = (unsigned long long *)ar.get((size_t)(nbuckets + 1 + 8) * 8), *start = (unsigned long long *)ar.get((size_t)(nbuckets + 1) * 8);
+    if (ar.rc) return ar.rc;
+    int *ctr = (int *)(cnt + nbuckets + 1);   // [0] most runs in one bucket
+    R3D_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)(nbuckets + 1 + 8) * 8, ctx->stream));
+    const int nb = (int)((n + 255) / 256);
+    k_cs_runs<KEY><<<nb, 256, 0, ctx->stream>>>(d_pts, n, g, keys, gid_of, cnt, runs);
+    int rc = dev_exclusive_scan<unsigned long long>(ctx, ar, cnt, start, nbuckets + 1, nullptr, ctr);
+    if (rc) return rc;
+    // ONE host round trip: the scan total (runs << 32 | points: cnt[nbuckets] is 0, so start[nbuckets] is the total) and the
+    // largest run count of a bucket, which decides whether the quadratic ranking step is affordable
+    struct { unsigned long long total; int max_runs; } h = {0, 0};
+    {
+        PinRead rd(ctx);
+        int prc;
+        if ((prc = rd.add(&h.total, start + nbuckets, 8)) || (prc = rd.add(&h.max_runs, ctr, 4)) || (prc = rd.wait())) return prc;
+    }
+    if ((int64_t)(unsigned)h.total != n) return r3d_fail(ctx, R3D_E_HIP, "counting sort: bucket populations sum to %u, expected %lld", (unsigned)h.total, (long long)n);
+    static const bool dbg = [] { const char *e = getenv("R3D_SORT_DEBUG"); return e && *e == '1'; }();
+    if (dbg) fprintf(stderr, "[r3d sort] n=%lld key_order=%d buckets=%lld runs=%d max_runs_per_bucket=%d keys%d\n", (long long)n, g.key_order,
+                     (long long)nbuckets, (int)(h.total >> 32), h.max_runs, (int)sizeof(KEY) * 8);
+    if (h.max_runs > CS_MAX_RUNS) return R3D_OK;
+    const int nruns = (int)(h.total >> 32), nrb = (nruns + 255) / 256;
+    k_cs_place<KEY><<<nb, 256, 0, ctx->stream>>>(runs, gid_of, n, start, placed);
+    k_cs_rank<KEY><<<nrb, 256, 0, ctx->stream>>>(placed, nruns, start, final_base);
+    k_cs_emit<KEY><<<nb, 256, 0, ctx->stream>>>(keys, gid_of, final_base, n, keys_out, idx_out, d_pts, sorted_pts);
+    R3D_HIP(ctx, hipGetLastError());
+    *keys_sorted = keys_out;
+    *idx_sorted = idx_out;
+    *done = true;
+    return R3D_OK;
+}
+
+// sorts point indices by (cell key, index); fills keys_sorted / idx_sorted (device) and, if sorted_pts != NULL, the points in that
+// order.  The keys are 32-bit whenever the key space allows; *keys32 tells the caller which type keys_sorted points to.
+// Default: the run-based counting sort above; the library radix sort when that declines.
 int sort_by_cell(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, const double org[3], double cell, const int dims[3],
-                 int key_order, void **keys_sorted, bool *keys32, int **idx_sorted) {
+                 int key_order, void **keys_sorted, bool *keys32, int **idx_sorted, double *sorted_pts = nullptr, int impl = -1) {
     int bits = 1;
     if (key_order == 2) {
         int m = std::max(dims[0], std::max(dims[1], dims[2])), b1 = 1;
@@ -1389,8 +1822,43 @@ int sort_by_cell(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, con
         while (bits < 64 && (maxkey >> bits)) bits++;
     }
     *keys32 = bits <= 32;
-    return *keys32 ? sort_by_cell_t<unsigned>(ctx, ar, d_pts, n, org, cell, dims, key_order, bits, keys_sorted, idx_sorted)
-                   : sort_by_cell_t<unsigned long long>(ctx, ar, d_pts, n, org, cell, dims, key_order, bits, keys_sorted, idx_sorted);
+    static const bool env_radix = [] { const char *e = getenv("R3D_SORT_IMPL"); return e && !strcmp(e, "radix"); }();
+    const bool force_radix = impl < 0 ? env_radix : impl == 1;
+    // bucket table of the counting sort: a monotone coarsening of the key (consecutive keys share a bucket) with about half as
+    // many entries as there are points (2^14 .. 2^26): small enough to fill and scan in a few microseconds, fine enough that a
+    // bucket holds tens of runs (the ranking step is quadratic in the runs of a bucket: whole (kx, ky) columns of an 8 MP view,
+    // pierced lengthwise by a slanted surface, held up to 1 500)
+    CsGeom g{org[0], org[1], org[2], cell, dims[0], dims[1], dims[2], key_order, 0, 1};
+    int64_t nbuckets;
+    int tb = 14;
+    // voxel keys of image-ordered clouds arrive in runs of several points (n / 2 buckets); search-grid and Morton keys of an
+    // unordered cloud are one run per point, so the ranking step wants few points per bucket (2 n buckets)
+    const int64_t want = (key_order == 1 || key_order == 3) ? n / 2 : 2 * n;
+    while (tb < 26 && (1ll << tb) < want) tb++;
+    if (key_order == 1 || key_order == 3) {
+        const long double total = (long double)dims[0] * dims[1] * dims[2];
+        unsigned long long d = (unsigned long long)(total / (long double)(1ll << tb)) + 1;
+        g.shift = -1;
+        g.div = d;
+        nbuckets = (int64_t)(total / (long double)d) + 2;
+    } else {
+        g.shift = std::max(0, bits - tb);
+        nbuckets = key_order == 2 ? (1ll << (bits - g.shift)) : (int64_t)(((unsigned long long)dims[0] * dims[1] * dims[2]) >> g.shift) + 1;
+    }
+    if (!force_radix && nbuckets <= CS_MAX_BUCKETS && n < 0x7fffffff) {
+        bool done = false;
+        const int rc = *keys32 ? counting_sort_by_cell_t<unsigned>(ctx, ar, d_pts, n, g, nbuckets, keys_sorted, idx_sorted, sorted_pts, &done)
+                               : counting_sort_by_cell_t<unsigned long long>(ctx, ar, d_pts, n, g, nbuckets, keys_sorted, idx_sorted, sorted_pts, &done);
+        if (rc || done) return rc;
+    }
+    const int rc = *keys32 ? radix_sort_by_cell_t<unsigned>(ctx, ar, d_pts, n, org, cell, dims, key_order, bits, keys_sorted, idx_sorted)
+                           : radix_sort_by_cell_t<unsigned long long>(ctx, ar, d_pts, n, org, cell, dims, key_order, bits, keys_sorted, idx_sorted);
+    if (rc) return rc;
+    if (sorted_pts) {
+        k_gather3<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(d_pts, *idx_sorted, n, sorted_pts);
+        R3D_HIP(ctx, hipGetLastError());
+    }
+    return R3D_OK;
 }
 
 // Builds the search grid.  cell_hint: minimum useful cell (search radius, or <= 0 for pure kNN); the cell is
@@ -1423,11 +1891,12 @@ int grid_build(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, doubl
     G.n = n;
     G.ncells = (int64_t)dims[0] * dims[1] * dims[2];
     int *idx;
-    rc = sort_by_cell(ctx, ar, d_pts, n, G.mn, cell, dims, 0, &G.keys, &G.keys32, &idx);
+    double *sorted = (double *)ar.get((size_t)n * 24);
+    if (ar.rc) return ar.rc;
+    rc = sort_by_cell(ctx, ar, d_pts, n, G.mn, cell, dims, 0, &G.keys, &G.keys32, &idx, sorted);   // writes the cell-sorted copy as well
     if (rc) return rc;
     int *cnt = (int *)ar.get((size_t)(G.ncells + 1) * 4), *rs = (int *)ar.get((size_t)(G.ncells + 1) * 4);
     int *cs = (int *)ar.get((size_t)(G.ncells + 1 + 4) * 4);   // + 4: nn_block_global reads 16 bytes at a run's first cell
-    double *sorted = (double *)ar.get((size_t)n * 24);
     if (ar.rc) return ar.rc;
     R3D_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)(G.ncells + 1) * 4, ctx->stream));
     const int nb = (int)((n + 255) / 256);
@@ -1438,15 +1907,7 @@ int grid_build(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, doubl
         k_cell_counts<unsigned long long><<<nb, 256, 0, ctx->stream>>>((const unsigned long long *)G.keys, n, rs, cnt);
         k_cell_counts2<unsigned long long><<<nb, 256, 0, ctx->stream>>>((const unsigned long long *)G.keys, n, rs, cnt);
     }
-    {
-        size_t tb = 0;
-        R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, cs, (int)(G.ncells + 1), ctx->stream));
-        void *tmp = ar.get(tb);
-        if (ar.rc) return ar.rc;
-        R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, cs, (int)(G.ncells + 1), ctx->stream));
-    }
-    k_gather3<<<nb, 256, 0, ctx->stream>>>(d_pts, idx, n, sorted);
-    R3D_HIP(ctx, hipGetLastError());
+    if ((rc = dev_exclusive_scan<int>(ctx, ar, cnt, cs, G.ncells + 1))) return rc;
     G.v = GridView{G.mn[0], G.mn[1], G.mn[2], cell, 1.0 / cell, dims[0], dims[1], dims[2], cs, sorted, idx, nullptr, nullptr, nullptr, 0.f, nullptr};
     return R3D_OK;
 }
@@ -1667,15 +2128,13 @@ int reproject_core(r3d_ctx *ctx, DevArena &ar, const int16_t *d_d, int w, int h,
     const int nb = (int)((n + 255) / 256);
     if (max_depth > 0) k_disp_flags_depth<<<nb, 256, 0, ctx->stream>>>(d_d, w, n, min_valid_x16, Q, max_depth, flags);
     else k_disp_flags<<<nb, 256, 0, ctx->stream>>>(d_d, n, min_valid_x16, flags);
-    size_t tb = 0;
-    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flags, scan, (int)n, ctx->stream));
-    void *tmp = ar.get(tb);
-    if (ar.rc) return ar.rc;
-    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tb, flags, scan, (int)n, ctx->stream));
+    if (int src = dev_exclusive_scan<int>(ctx, ar, flags, scan, n)) return src;
     int ls = 0, lf = 0;
-    R3D_HIP(ctx, hipMemcpyAsync(&ls, scan + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    R3D_HIP(ctx, hipMemcpyAsync(&lf, flags + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        PinRead rd(ctx);
+        int prc;
+        if ((prc = rd.add(&ls, scan + (n - 1), 4)) || (prc = rd.add(&lf, flags + (n - 1), 4)) || (prc = rd.wait())) return prc;
+    }
     const int64_t m = (int64_t)ls + lf;
     *m_out = m;
     *d_xyz_out = nullptr;
@@ -1706,15 +2165,13 @@ int backproject_core(r3d_ctx *ctx, DevArena &ar, const uint16_t *depth, int w, i
     DepthCam c{cam->fx, cam->fy, cam->ppx, cam->ppy, cam->depth_trunc, (float)cam->depth_scale, cam->flip_yz};
     const int nb = (int)((n + 255) / 256);
     k_depth_flags<<<nb, 256, 0, ctx->stream>>>(d_d, w, stride, n, c, flags);
-    size_t tb = 0;
-    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flags, scan, (int)n, ctx->stream));
-    void *tmp = ar.get(tb);
-    if (ar.rc) return ar.rc;
-    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tb, flags, scan, (int)n, ctx->stream));
+    if (int src = dev_exclusive_scan<int>(ctx, ar, flags, scan, n)) return src;
     int ls = 0, lf = 0;
-    R3D_HIP(ctx, hipMemcpyAsync(&ls, scan + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    R3D_HIP(ctx, hipMemcpyAsync(&lf, flags + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        PinRead rd(ctx);
+        int prc;
+        if ((prc = rd.add(&ls, scan + (n - 1), 4)) || (prc = rd.add(&lf, flags + (n - 1), 4)) || (prc = rd.wait())) return prc;
+    }
     const int64_t m = (int64_t)ls + lf;
     *m_out = m;
     *d_xyz_out = nullptr;
@@ -1742,6 +2199,7 @@ static int depth_args_ok(r3d_ctx *ctx, const uint16_t *depth, int w, int h, int 
 // voxel grid of a device cloud: segments of equal legacy voxel index, in lexicographic index order
 struct VoxelSegs {
     int *idx = nullptr, *starts = nullptr;
+    double *sorted = nullptr;   // the points in (voxel, index) order (written by the sort)
     int64_t nseg = 0;
 };
 int voxel_segments(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, double voxel, VoxelSegs &V, bool tensor_grid = false) {
@@ -1767,23 +2225,23 @@ int voxel_segments(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, dou
     void *keys;
     bool keys32;
     // key_order 1: exact legacy index floor((p - origin) / voxel), z fastest => output in lexicographic (kx,ky,kz) order
-    if ((rc = sort_by_cell(ctx, ar, d_p, n, org, voxel, dims, tensor_grid ? 3 : 1, &keys, &keys32, &V.idx))) return rc;
+    V.sorted = (double *)ar.get((size_t)n * 24);
+    if (ar.rc) return ar.rc;
+    if ((rc = sort_by_cell(ctx, ar, d_p, n, org, voxel, dims, tensor_grid ? 3 : 1, &keys, &keys32, &V.idx, V.sorted))) return rc;
     int *flags = (int *)ar.get((size_t)n * 4), *scan = (int *)ar.get((size_t)n * 4);
     V.starts = (int *)ar.get((size_t)n * 4);
     if (ar.rc) return ar.rc;
     const int nb = (int)((n + 255) / 256);
     if (keys32) k_seg_flags<unsigned><<<nb, 256, 0, ctx->stream>>>((const unsigned *)keys, n, flags);
     else k_seg_flags<unsigned long long><<<nb, 256, 0, ctx->stream>>>((const unsigned long long *)keys, n, flags);
-    size_t tb = 0;
-    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flags, scan, (int)n, ctx->stream));
-    void *tmp = ar.get(tb);
-    if (ar.rc) return ar.rc;
-    R3D_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tb, flags, scan, (int)n, ctx->stream));
+    if (int src = dev_exclusive_scan<int>(ctx, ar, flags, scan, n)) return src;
     k_seg_starts<<<nb, 256, 0, ctx->stream>>>(flags, scan, n, V.starts);
     int last_scan = 0, last_flag = 0;
-    R3D_HIP(ctx, hipMemcpyAsync(&last_scan, scan + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    R3D_HIP(ctx, hipMemcpyAsync(&last_flag, flags + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        PinRead rd(ctx);
+        int prc;
+        if ((prc = rd.add(&last_scan, scan + (n - 1), 4)) || (prc = rd.add(&last_flag, flags + (n - 1), 4)) || (prc = rd.wait())) return prc;
+    }
     V.nseg = (int64_t)last_scan + last_flag;
     return R3D_OK;
 }
@@ -2008,13 +2466,11 @@ static int voxel_downsample_impl(r3d_ctx *ctx, const double *xyz, const double *
     const int64_t nseg = V.nseg;
     double *d_out = (double *)ar.get((size_t)nseg * 24);
     if (ar.rc) return ar.rc;
-    const int nbs = (int)((nseg + 255) / 256);
     const double *ins[3] = {d_p, d_c, d_n};
     double *outs[3] = {out_xyz, out_colors, out_normals};
     for (int a = 0; a < 3; a++) {
         if (!ins[a]) continue;
-        if (tensor_grid) k_voxel_mean_f32<<<nbs, 256, 0, ctx->stream>>>(ins[a], V.idx, V.starts, nseg, n, d_out);
-        else k_voxel_mean<<<nbs, 256, 0, ctx->stream>>>(ins[a], V.idx, V.starts, nseg, n, d_out);
+        if ((rc = launch_voxel_mean(ctx, ar, tensor_grid, ins[a], V.idx, V.starts, nseg, n, d_out, a == 0 ? V.sorted : nullptr))) return rc;
         R3D_HIP(ctx, hipGetLastError());
         R3D_HIP(ctx, hipMemcpyAsync(outs[a], d_out, (size_t)nseg * 24, hipMemcpyDeviceToHost, ctx->stream));
         R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -2118,7 +2574,7 @@ static int disparity_to_cloud_impl(r3d_ctx *ctx, const int16_t *d_disp, int32_t 
         if ((rc = voxel_segments(ctx, ar, d_p, m, voxel, V))) return rc;
         double *d_v = (double *)ar.get((size_t)V.nseg * 24);
         if (ar.rc) return ar.rc;
-        k_voxel_mean<<<(unsigned)((V.nseg + 255) / 256), 256, 0, ctx->stream>>>(d_p, V.idx, V.starts, V.nseg, m, d_v);
+        if ((rc = launch_voxel_mean(ctx, ar, false, d_p, V.idx, V.starts, V.nseg, m, d_v, V.sorted))) return rc;
         R3D_HIP(ctx, hipGetLastError());
         d_p = d_v;
         m = V.nseg;
@@ -2179,8 +2635,8 @@ int r3d_align_point_clouds(r3d_ctx *ctx, const r3d_align_params *p, const double
         if ((rc = voxel_segments(ctx, ar, d_s, ns, p->voxel_size, V))) return rc;
         double *d_sv = (double *)ar.get((size_t)V.nseg * 24), *d_cv = d_c ? (double *)ar.get((size_t)V.nseg * 24) : nullptr;
         if (ar.rc) return ar.rc;
-        k_voxel_mean<<<(unsigned)((V.nseg + 255) / 256), 256, 0, ctx->stream>>>(d_s, V.idx, V.starts, V.nseg, ns, d_sv);
-        if (d_c) k_voxel_mean<<<(unsigned)((V.nseg + 255) / 256), 256, 0, ctx->stream>>>(d_c, V.idx, V.starts, V.nseg, ns, d_cv);
+        if ((rc = launch_voxel_mean(ctx, ar, false, d_s, V.idx, V.starts, V.nseg, ns, d_sv, V.sorted))) return rc;
+        if (d_c) if ((rc = launch_voxel_mean(ctx, ar, false, d_c, V.idx, V.starts, V.nseg, ns, d_cv))) return rc;
         R3D_HIP(ctx, hipGetLastError());
         d_s = d_sv;
         d_c = d_cv;
@@ -2189,7 +2645,7 @@ int r3d_align_point_clouds(r3d_ctx *ctx, const r3d_align_params *p, const double
         if ((rc = voxel_segments(ctx, ar, d_t, nt, p->voxel_size, Vt))) return rc;
         double *d_tv = (double *)ar.get((size_t)Vt.nseg * 24);
         if (ar.rc) return ar.rc;
-        k_voxel_mean<<<(unsigned)((Vt.nseg + 255) / 256), 256, 0, ctx->stream>>>(d_t, Vt.idx, Vt.starts, Vt.nseg, nt, d_tv);
+        if ((rc = launch_voxel_mean(ctx, ar, false, d_t, Vt.idx, Vt.starts, Vt.nseg, nt, d_tv, Vt.sorted))) return rc;
         R3D_HIP(ctx, hipGetLastError());
         d_t = d_tv;
         mt = Vt.nseg;
@@ -2555,8 +3011,8 @@ int model_align_core(r3d_model *m, DevArena &ar, const r3d_align_params *p, doub
         if ((rc = voxel_segments(ctx, ar, d_s, ns, p->voxel_size, V))) return rc;
         double *d_sv = (double *)ar.get((size_t)V.nseg * 24), *d_cv = d_c ? (double *)ar.get((size_t)V.nseg * 24) : nullptr;
         if (ar.rc) return ar.rc;
-        k_voxel_mean<<<(unsigned)((V.nseg + 255) / 256), 256, 0, ctx->stream>>>(d_s, V.idx, V.starts, V.nseg, ns, d_sv);
-        if (d_c) k_voxel_mean<<<(unsigned)((V.nseg + 255) / 256), 256, 0, ctx->stream>>>(d_c, V.idx, V.starts, V.nseg, ns, d_cv);
+        if ((rc = launch_voxel_mean(ctx, ar, false, d_s, V.idx, V.starts, V.nseg, ns, d_sv, V.sorted))) return rc;
+        if (d_c) if ((rc = launch_voxel_mean(ctx, ar, false, d_c, V.idx, V.starts, V.nseg, ns, d_cv))) return rc;
         R3D_HIP(ctx, hipGetLastError());
         d_s = d_sv;
         d_c = d_cv;
@@ -2565,7 +3021,7 @@ int model_align_core(r3d_model *m, DevArena &ar, const r3d_align_params *p, doub
         if ((rc = voxel_segments(ctx, ar, d_t, m->n, p->voxel_size, Vt))) return rc;
         double *d_tv = (double *)ar.get((size_t)Vt.nseg * 24);
         if (ar.rc) return ar.rc;
-        k_voxel_mean<<<(unsigned)((Vt.nseg + 255) / 256), 256, 0, ctx->stream>>>(d_t, Vt.idx, Vt.starts, Vt.nseg, m->n, d_tv);
+        if ((rc = launch_voxel_mean(ctx, ar, false, d_t, Vt.idx, Vt.starts, Vt.nseg, m->n, d_tv, Vt.sorted))) return rc;
         R3D_HIP(ctx, hipGetLastError());
         d_t = d_tv;
         mt = Vt.nseg;
@@ -2775,3 +3231,34 @@ int r3d_transform_points_dev(r3d_ctx *ctx, const double *d_xyz, int64_t n, const
 }
 
 }  // extern "C"
+
+// diagnostic: the cell sort on its own (tests compare both implementations with a host lexsort)
+extern "C" int r3d_debug_sort_by_cell(r3d_ctx *ctx, const double *xyz, int64_t n, const double *org3, double cell, const int32_t *dims3, int32_t key_order,
+                                      int32_t impl, int32_t *idx_out, uint64_t *keys_out) {
+    R3D_ROCTX_RANGE("r3d_debug_sort_by_cell");
+    if (!ctx) return R3D_E_BADARG;
+    if (!xyz || !org3 || !dims3 || !idx_out || n <= 0 || !(cell > 0) || key_order < 0 || key_order > 3 || impl < 0 || impl > 1)
+        return r3d_fail(ctx, R3D_E_BADARG, "debug_sort_by_cell: bad argument");
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    DevArena ar(ctx);
+    double *d_p;
+    int rc;
+    if ((rc = upload(ctx, ar, xyz, n * 3, &d_p))) return rc;
+    const int dims[3] = {dims3[0], dims3[1], dims3[2]};
+    void *keys;
+    bool k32;
+    int *idx;
+    if ((rc = sort_by_cell(ctx, ar, d_p, n, org3, cell, dims, key_order, &keys, &k32, &idx, nullptr, impl))) return rc;
+    R3D_HIP(ctx, hipMemcpyAsync(idx_out, idx, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<unsigned> k4;
+    if (keys_out) {
+        if (k32) {
+            k4.resize((size_t)n);
+            R3D_HIP(ctx, hipMemcpyAsync(k4.data(), keys, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        } else R3D_HIP(ctx, hipMemcpyAsync(keys_out, keys, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (keys_out && k32)
+        for (int64_t i = 0; i < n; i++) keys_out[i] = k4[(size_t)i];
+    return R3D_OK;
+}

@@ -15,6 +15,7 @@ struct r3d_buf {
 };
 
 #define R3D_MAX_PROF 16
+#define R3D_PIN_BYTES 65536
 #define R3D_MAX_DEVICES 64   /* per-device caches of launch geometry */
 #define R3D_PROF_SETS 4
 
@@ -67,6 +68,8 @@ struct r3d_ctx {
     std::vector<r3d_buf> cloud_bufs;
     hipEvent_t icp_ev = nullptr;   // polled once per registration iteration
     double *icp_host = nullptr;    // pinned landing buffer of the per-iteration sums
+    hipEvent_t pin_ev = nullptr;   // completion of a PinRead (polled briefly, then waited for)
+    void *pin = nullptr;           // pinned landing buffer of the small device -> host reads between kernels (R3D_PIN_BYTES)
     // pre/post-processing workspace (prepost.hip)
     std::vector<r3d_buf> pp_bufs;
     r3d_buf pp_minmax, pp_lut;

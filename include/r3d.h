@@ -47,6 +47,11 @@ void *r3d_get_stream(r3d_ctx *ctx);
 int r3d_stream_wait_event(r3d_ctx *ctx, void *hip_event);
 /* diagnostic: prices an access shape (rows independent streams of row_bytes; mode 0 = 256 B, 1 = 1 KB per wave request) */
 int r3d_debug_streambench(r3d_ctx *ctx, int32_t mode, int32_t rows, uint64_t row_bytes, int32_t write, int32_t delay, int32_t reps, float *ms);
+/* diagnostic: the stable sort of point indices by (cell key, index) that every grid / voxel build starts with.  key_order 0: x
+ * fastest (search grid), 1: legacy voxel index (z fastest), 2: Morton code of the cell, 3: tensor voxel index; impl 0: the
+ * hand-written run-based counting sort (default path), 1: the library radix sort (fallback path).  keys_out may be NULL. */
+int r3d_debug_sort_by_cell(r3d_ctx *ctx, const double *xyz, int64_t n, const double *org3, double cell, const int32_t *dims3, int32_t key_order,
+                           int32_t impl, int32_t *idx_out, uint64_t *keys_out);
 /* checks the cross-lane primitives (DPP shifts, permlane swaps, wave reductions) the kernels rely on */
 int r3d_selftest(r3d_ctx *ctx);
 

@@ -596,3 +596,55 @@ def test_scanning_loop_from_depth_images_equals_loop_over_clouds(r3d):
     np.testing.assert_array_equal(got.points, want.points)
     np.testing.assert_array_equal(got.colors, want.colors)
     assert r3d.pipeline.fuse_depth_frames([None, far], cam).points.shape == (0, 3)
+
+
+# ------------------------------------------------------------------ the hand-written stable counting sort behind every grid build
+def _host_keys(p, org, cell, dims, order):
+    nx, ny, nz = dims
+    if order == 1:
+        c = np.floor((p - org) / cell).astype(np.int64)
+    else:
+        c = np.floor((p - org) * (1.0 / cell)).astype(np.int64)
+    c = np.clip(c, 0, np.array(dims) - 1)
+    if order == 0:
+        return (c[:, 2] * ny + c[:, 1]) * nx + c[:, 0]
+    if order == 1:
+        return (c[:, 0] * ny + c[:, 1]) * nz + c[:, 2]
+
+    def spread(v):
+        out = np.zeros_like(v)
+        for b in range(21):
+            out |= ((v >> b) & 1) << (3 * b)
+        return out
+    return spread(c[:, 0]) | spread(c[:, 1]) << 1 | spread(c[:, 2]) << 2
+
+
+@pytest.mark.parametrize("case", ["random_x_fastest", "voxel_raster_runs", "morton", "tiny", "one_bucket_many_runs", "wide_keys"])
+def test_counting_sort_is_the_stable_key_index_order(r3d, case):
+    """the run-based counting sort (k_cs_runs / place / rank / emit) must produce THE stable order by
+    (cell key, original index) -- what a host lexsort gives and what the library radix sort (kept as the fallback) gives."""
+    rng = np.random.default_rng(11)
+    org = np.array([-1.0, -2.0, 0.5])
+    if case == "random_x_fastest":
+        p, cell, dims, order = org + rng.random((200_003, 3)) * [3.0, 2.0, 1.0], 0.01, (301, 201, 101), 0
+    elif case == "voxel_raster_runs":      # pixels of an image in raster order: long runs of equal voxel keys
+        u, v = np.meshgrid(np.arange(1500), np.arange(700))
+        z = 1.0 + 0.2 * np.sin(u / 90.0) * np.cos(v / 70.0)
+        p = org + np.stack([u.ravel() * 0.0008 * z.ravel(), v.ravel() * 0.0008 * z.ravel(), z.ravel() - 0.7], 1)
+        cell, dims, order = 0.01, (160, 80, 80), 1
+    elif case == "morton":
+        p, cell, dims, order = org + rng.random((70_001, 3)) * [1.0, 1.0, 1.0], 0.004, (251, 251, 251), 2
+    elif case == "tiny":
+        p, cell, dims, order = org + rng.random((1, 3)), 0.5, (3, 3, 3), 0
+    elif case == "one_bucket_many_runs":    # > 4096 single-point runs in ONE voxel column: the counting sort declines, radix takes over
+        p = np.tile(org + [0.005, 0.005, 0.0], (12_000, 1))
+        p[:, 2] += 0.01 * (np.arange(12_000) % 7) + 0.005
+        cell, dims, order = 0.01, (4, 4, 16), 1
+    else:                                   # key space beyond 32 bits: 64-bit keys
+        p, cell, dims, order = org + rng.random((50_000, 3)) * [2.0, 2.0, 2.0], 0.001, (2001, 2001, 2001), 1
+    want_keys = _host_keys(p, org, cell, dims, order)
+    want = np.lexsort((np.arange(len(p)), want_keys))
+    for impl in (0, 1):
+        idx, keys = r3d.cloud_ops.debug_sort_by_cell(p, org, cell, dims, order, impl)
+        np.testing.assert_array_equal(idx, want)
+        np.testing.assert_array_equal(keys.astype(np.int64), want_keys[want])
