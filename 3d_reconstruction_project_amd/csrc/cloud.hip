@@ -28,8 +28,16 @@ namespace {
 struct GridView {
     double ox, oy, oz, cell, inv_cell;
     int nx, ny, nz;
-    const int *cstart;     // [ncells + 1] first sorted slot of every cell (exclusive scan of the cell populations);
-                           // x is the fastest key digit, so cells adjacent in x hold ONE contiguous run of points
+    // Cell table, two levels.  cstart(c) = number of points whose cell index is below c = first sorted slot of cell c (x is the
+    // fastest key digit, so cells adjacent in x hold ONE contiguous run of points).  The linear cell index is cut into LINES of 32
+    // cells; l1[line] >= 0: no point in cells [32 line, 32 line + 36): all those cells share that cstart value;
+    // l1[line] < 0: the line is materialised as l2[(-l1 - 1) * 36 + w], w = 0 .. 35 (the last four entries repeat the first four
+    // cells of the next line, so a 16-byte read of four consecutive entries never leaves its line).  A surface occupies a few per
+    // cent of a dense grid: at 1 M points the dense int table was 144 MB and most of a query's L2 misses; l1 is 4.5 MB, l2 ~15 MB.
+    const int *l1, *l2;
+    // ... or, when `dense` is set, the plain table dense[c] = cstart(c), c = 0 .. ncells + 4 (no dependent second load: what the
+    // registration loop's search uses; its set-up pays three passes over the whole table instead)
+    const int *dense;
     const double *pts;     // [n][3] points in cell-sorted order
     const int *idx;        // [n] sorted slot -> original index
     // optional float32 structure-of-arrays copy of pts (n + 4 entries each) for the two-stage 1-NN search of the
@@ -42,6 +50,25 @@ struct GridView {
 };
 
 __device__ __forceinline__ int cell_coord(double v, double o, double inv) { return (int)floor((v - o) * inv); }
+
+constexpr int CL_SHIFT = 5, CL_STRIDE = 36;
+typedef int cs_int4 __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte global load
+// loads are issued unconditionally from a clamped address and selected afterwards (a branch around a load costs a wait per load)
+__device__ __forceinline__ int cs1(const GridView &g, int64_t c) {
+    if (g.dense) return g.dense[c];   // wave-uniform branch
+    const int v = g.l1[c >> CL_SHIFT];
+    const int e = g.l2[(int64_t)(v < 0 ? -v - 1 : 0) * CL_STRIDE + (int)(c & 31)];
+    return v < 0 ? e : v;
+}
+// cstart of the four consecutive cells c .. c + 3
+__device__ __forceinline__ cs_int4 cs4(const GridView &g, int64_t c) {
+    if (g.dense) return *(const cs_int4 *)(g.dense + c);   // wave-uniform branch
+    const int v = g.l1[c >> CL_SHIFT];
+    const cs_int4 e = *(const cs_int4 *)(g.l2 + (int64_t)(v < 0 ? -v - 1 : 0) * CL_STRIDE + (int)(c & 31));
+    cs_int4 r;
+    r.x = v < 0 ? e.x : v; r.y = v < 0 ? e.y : v; r.z = v < 0 ? e.z : v; r.w = v < 0 ? e.w : v;
+    return r;
+}
 
 // ------------------------------------------------------------------------------------------------ bbox
 __global__ void __launch_bounds__(256) k_bbox_partial(const double *__restrict__ p, int64_t n, double *__restrict__ part) {
@@ -135,27 +162,35 @@ __global__ void __launch_bounds__(256) k_gather3(const double *__restrict__ src,
 // the result does not depend on the order, so it is deterministic.  T = int (flags, cell populations) or unsigned long long
 // (two counters packed: points in the low word, runs in the high word; both stay below 2^31 so no carry crosses).
 constexpr int SCAN_T = 256, SCAN_I = 16, SCAN_TILE = SCAN_T * SCAN_I;
-template <class T>
+// MAXOP: the running maximum instead of the running sum (values >= 0; used to carry "points so far" across empty table lines)
+template <class T, bool MAXOP = false>
+__device__ __forceinline__ T scan_op(T a, T b) { return MAXOP ? (a > b ? a : b) : a + b; }
+template <class T, bool MAXOP = false>
 __device__ __forceinline__ T wave_incl_scan(T v, int lane) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const T t = __shfl_up(v, o);
-        if (lane >= o) v += t;
+        if (lane >= o) v = scan_op<T, MAXOP>(v, t);
     }
     return v;
 }
 // one value per thread of a 256-thread workgroup -> exclusive prefix; *total = workgroup sum
-template <class T>
+template <class T, bool MAXOP = false>
 __device__ __forceinline__ T block_excl_scan(T v, T *total, T *ws /* 4 entries of LDS */) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const T incl = wave_incl_scan<T>(v, lane);
+    const T incl = wave_incl_scan<T, MAXOP>(v, lane);
     if (lane == 63) ws[w] = incl;
     __syncthreads();
     T off = 0, tot = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) { if (i < w) off += ws[i]; tot += ws[i]; }
+    for (int i = 0; i < 4; i++) { if (i < w) off = scan_op<T, MAXOP>(off, ws[i]); tot = scan_op<T, MAXOP>(tot, ws[i]); }
     __syncthreads();
     *total = tot;
+    if (MAXOP) {   // exclusive = the inclusive value of the lane before (0 for the first lane of the wave), joined with the waves before
+        T prev = __shfl_up(incl, 1);
+        if (lane == 0) prev = 0;
+        return scan_op<T, true>(off, prev);
+    }
     return off + incl - v;
 }
 // 16 consecutive elements of a thread as 16-byte accesses when the whole group is inside the array (the arrays come from the arena:
@@ -177,27 +212,27 @@ __device__ __forceinline__ void scan_load16(const T *__restrict__ in, int64_t ba
         for (int j = 0; j < SCAN_I; j++) v[j] = base + j < n ? in[base + j] : (T)0;
     }
 }
-template <class T>
+template <class T, bool MAXOP = false>
 __global__ void __launch_bounds__(SCAN_T) k_scan_sums(const T *__restrict__ in, int64_t n, T *__restrict__ part) {
     __shared__ T ws[4];
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_I;
     T v[SCAN_I], s = 0;
     scan_load16<T>(in, base, n, v);
 #pragma unroll
-    for (int j = 0; j < SCAN_I; j++) s += v[j];
+    for (int j = 0; j < SCAN_I; j++) s = scan_op<T, MAXOP>(s, v[j]);
     T tot;
-    (void)block_excl_scan<T>(s, &tot, ws);
+    (void)block_excl_scan<T, MAXOP>(s, &tot, ws);
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
 // hi_max (T = unsigned long long only): the largest HIGH word of any input element (runs per bucket), by atomicMax
-template <class T>
+template <class T, bool MAXOP = false>
 __global__ void __launch_bounds__(SCAN_T) k_scan_apply(const T *__restrict__ in, int64_t n, const T *__restrict__ part, T *__restrict__ out,
                                                        int *__restrict__ lo_out, int *__restrict__ hi_max) {
     __shared__ T ws[4];
     T acc = 0;
-    for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_T) acc += part[b];
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_T) acc = scan_op<T, MAXOP>(acc, part[b]);
     T tile_off;
-    (void)block_excl_scan<T>(acc, &tile_off, ws);
+    (void)block_excl_scan<T, MAXOP>(acc, &tile_off, ws);
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_I;
     T v[SCAN_I], s = 0;
     int hm = 0;
@@ -205,10 +240,10 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_apply(const T *__restrict__ in,
 #pragma unroll
     for (int j = 0; j < SCAN_I; j++) {
         if (sizeof(T) == 8) hm = max(hm, (int)((unsigned long long)v[j] >> 32));
-        s += v[j];
+        s = scan_op<T, MAXOP>(s, v[j]);
     }
     T tot;
-    T run = tile_off + block_excl_scan<T>(s, &tot, ws);
+    T run = scan_op<T, MAXOP>(tile_off, block_excl_scan<T, MAXOP>(s, &tot, ws));
     if (base + SCAN_I <= n && !lo_out) {
         constexpr int PER = 16 / sizeof(T);
         typedef T vec_t __attribute__((ext_vector_type(PER)));
@@ -217,7 +252,7 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_apply(const T *__restrict__ in,
         for (int q = 0; q < SCAN_I / PER; q++) {
             vec_t t;
 #pragma unroll
-            for (int c = 0; c < PER; c++) { t[c] = run; run += v[q * PER + c]; }
+            for (int c = 0; c < PER; c++) { t[c] = run; run = scan_op<T, MAXOP>(run, v[q * PER + c]); }
             p[q] = t;
         }
     } else {
@@ -227,7 +262,7 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_apply(const T *__restrict__ in,
                 out[base + j] = run;
                 if (lo_out) lo_out[base + j] = (int)(unsigned)run;
             }
-            run += v[j];
+            run = scan_op<T, MAXOP>(run, v[j]);
         }
     }
     if (sizeof(T) == 8 && hi_max) {
@@ -381,6 +416,54 @@ __global__ void __launch_bounds__(256) k_cs_emit(const KEY *__restrict__ keys, c
     if (sorted) { sorted[o * 3] = pts[i * 3]; sorted[o * 3 + 1] = pts[i * 3 + 1]; sorted[o * 3 + 2] = pts[i * 3 + 2]; }
 }
 
+// ================================================================================== two-level cell table (GridView::l1 / l2)
+// Built from the SORTED keys.  k_line_mark: which lines hold a point in their 36-cell reach, and, per line, one past the sorted
+// slot of its last point (so that an exclusive running maximum over the lines gives "points before this line").  k_line_l1: the
+// first level.  k_line_fill: every run start i (first slot of a cell c, previous occupied cell p) owns the cells (p, c]: their
+// cstart is i; it writes that value into the materialised lines that reach into (p, c] -- those are the lines that contain p or
+// c in their 36-cell reach (a materialised line holds an occupied cell q; for an entry cc <= q the owner's c lies in [cc, q], for
+// cc > q its p lies in [q, cc): inside the line either way), at most four lines per run start.  Slot n is the virtual last
+// run start (c = +infinity).
+template <class KEY>
+__global__ void __launch_bounds__(256) k_line_mark(const KEY *__restrict__ keys, int64_t n, int *__restrict__ mark, int *__restrict__ last1) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long c = (long long)keys[i];
+    if (i == 0 || (long long)keys[i - 1] != c) {
+        mark[c >> CL_SHIFT] = 1;
+        if ((c & 31) < CL_STRIDE - 32 && c >= 32) mark[(c >> CL_SHIFT) - 1] = 1;
+    }
+    if (i == n - 1 || ((long long)keys[i + 1] >> CL_SHIFT) != (c >> CL_SHIFT)) last1[c >> CL_SHIFT] = (int)i + 1;
+}
+__global__ void __launch_bounds__(256) k_line_l1(const int *__restrict__ mark, const int *__restrict__ ids, const int *__restrict__ before,
+                                                 int64_t nl, int *__restrict__ l1) {
+    const int64_t L = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (L >= nl) return;
+    l1[L] = mark[L] ? -(ids[L] + 1) : before[L];
+}
+template <class KEY>
+__global__ void __launch_bounds__(256) k_line_fill(const KEY *__restrict__ keys, int64_t n, const int *__restrict__ l1, int64_t nl, int *__restrict__ l2) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i > n) return;
+    const long long p = i > 0 ? (long long)keys[i - 1] : -1, c = i < n ? (long long)keys[i] : (long long)nl * 32 + CL_STRIDE;
+    if (i < n && i > 0 && p == c) return;            // not a run start
+    long long cand[4] = {(p >> CL_SHIFT) - 1, p >> CL_SHIFT, (c >> CL_SHIFT) - 1, c >> CL_SHIFT};   // (p = -1: lines -2 and -1, skipped)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const long long L = cand[q];
+        bool dup = false;
+#pragma unroll
+        for (int r = 0; r < 4; r++) dup = dup || (r < q && cand[r] == L);
+        if (dup || L < 0 || L >= nl) continue;
+        const int v = l1[L];
+        if (v >= 0) continue;                        // not materialised
+        int *e = l2 + (int64_t)(-v - 1) * CL_STRIDE;
+        const long long c0 = L * 32;
+        const int w0 = (int)max(p + 1 - c0, 0ll), w1 = (int)min(c - c0, (long long)CL_STRIDE - 1);
+        for (int w = w0; w <= w1; w++) e[w] = (int)i;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ voxel
 // segment heads of the sorted key array -> compact list of segment starts (one output voxel per segment)
 template <class KEY>
@@ -510,7 +593,7 @@ __device__ __forceinline__ void for_shell(const GridView &g, int cx, int cy, int
                 int x = cx + dx;
                 if (x < 0 || x >= g.nx) continue;
                 int64_t c = ((int64_t)z * g.ny + y) * g.nx + x;
-                int b = g.cstart[c], e = g.cstart[c + 1];
+                int b = cs1(g, c), e = cs1(g, c + 1);
                 if (e > b) f(b, e);
             }
         }
@@ -529,7 +612,7 @@ __device__ __forceinline__ void for_block3(const GridView &g, int cx, int cy, in
             const int y = cy + dy;
             if (y < 0 || y >= g.ny) continue;
             const int64_t row = ((int64_t)z * g.ny + y) * g.nx;
-            const int b = g.cstart[row + x0], e = g.cstart[row + x1 + 1];
+            const int b = cs1(g, row + x0), e = cs1(g, row + x1 + 1);
             if (e > b) f(b, e);
         }
     }
@@ -569,7 +652,7 @@ __device__ __forceinline__ void for_shell_rows(const GridView &g, double px, dou
                 const int kx = rx < (double)s ? (int)rx + 1 : s;
                 const int x0 = max(cx - min(kx, s), 0), x1 = min(cx + min(kx, s), g.nx - 1);
                 if (x0 > x1) continue;
-                const int b = g.cstart[row + x0], e = g.cstart[row + x1 + 1];
+                const int b = cs1(g, row + x0), e = cs1(g, row + x1 + 1);
                 if (e > b) visit(b, e);
             } else {
 #pragma unroll
@@ -578,7 +661,7 @@ __device__ __forceinline__ void for_shell_rows(const GridView &g, double px, dou
                     if (x < 0 || x >= g.nx) continue;
                     const double sx = slab(px, g.ox, x);
                     if ((sx * sx + syz) * SLK > bound()) continue;
-                    const int b = g.cstart[row + x], e = g.cstart[row + x + 1];
+                    const int b = cs1(g, row + x), e = cs1(g, row + x + 1);
                     if (e > b) visit(b, e);
                 }
             }
@@ -917,6 +1000,9 @@ struct IcpState {
     double fit, rmse, corr;   // statistics of the latest evaluation
     int evals;                // evaluations consumed so far
     int done, converged, iterations;
+    // device clock (wall_clock64, 100 MHz) at the first and the latest step: the GPU-side duration of the loop, to tell a stall
+    // of the device from a completion that reached the host late (R3D_ICP_DEBUG=1 prints both when they disagree)
+    unsigned long long t_first, t_last;
 };
 __device__ __forceinline__ Rigid load_rigid(const IcpState *__restrict__ st) {
     Rigid T;
@@ -961,8 +1047,7 @@ __device__ __forceinline__ void nn_block_global(const GridView &g, double px, do
         const int64_t row = ((int64_t)min(max(z, 0), g.nz - 1) * g.ny + min(max(y, 0), g.ny - 1)) * g.nx;
         // both bounds of the run with ONE 16-byte request (the end entry is at most three behind the start entry; the table
         // is allocated with four spare entries); the search is bound by the number of cache-line requests, not by latency
-        typedef int int4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte global load
-        const int4_a4 cs = *(const int4_a4 *)(g.cstart + row + x0);
+        const cs_int4 cs = cs4(g, row + x0);
         const int b = cs.x, de = x1 + 1 - x0, e = de == 3 ? cs.w : de == 2 ? cs.z : cs.y;
         rb[r] = b;
         re[r] = b + ((e - b) & (ok ? -1 : 0));
@@ -1005,7 +1090,6 @@ __device__ __forceinline__ void nn_block_top4(const GridView &g, double px, doub
     const int xa = cx - 1, xb = cx + 1;
     const bool xok = xb >= 0 && xa <= g.nx - 1;
     const int x0 = min(max(xa, 0), g.nx - 1), x1 = min(max(xb, 0), g.nx - 1);
-    typedef int int4_a4 __attribute__((ext_vector_type(4), aligned(4)));
     typedef float float4_a4 __attribute__((ext_vector_type(4), aligned(4)));
     int rb[9], re[9];
 #pragma unroll
@@ -1013,7 +1097,7 @@ __device__ __forceinline__ void nn_block_top4(const GridView &g, double px, doub
         const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
         const bool ok = xok && z >= 0 && z < g.nz && y >= 0 && y < g.ny;
         const int64_t row = ((int64_t)min(max(z, 0), g.nz - 1) * g.ny + min(max(y, 0), g.ny - 1)) * g.nx;
-        const int4_a4 cs = *(const int4_a4 *)(g.cstart + row + x0);
+        const cs_int4 cs = cs4(g, row + x0);
         const int b = cs.x, de = x1 + 1 - x0, e = de == 3 ? cs.w : de == 2 ? cs.z : cs.y;
         rb[r] = b;
         re[r] = b + ((e - b) & (ok ? -1 : 0));
@@ -1128,7 +1212,6 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
     const int xa = cx - 1, xb = cx + 1;
     const bool xok = xb >= 0 && xa <= g.nx - 1;
     const int x0 = min(max(xa, 0), g.nx - 1), x1 = min(max(xb, 0), g.nx - 1);
-    typedef int int4_a4 __attribute__((ext_vector_type(4), aligned(4)));
     typedef unsigned uint4_a4 __attribute__((ext_vector_type(4), aligned(4)));
     constexpr int ORD[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};   // centre row, the four rows sharing a face with it, the four corners
     int rb[9], re[9], rm1[9], rm2[9], total = 0;   // run bounds and the two cell boundaries inside a full three-cell run
@@ -1141,7 +1224,7 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
         const int r = ORD[q], rz = r / 3, ry = r % 3;
         const bool ok = xok && (unsigned)(cz + rz - 1) < (unsigned)g.nz && (unsigned)(cy + ry - 1) < (unsigned)g.ny;
         const unsigned off = ((unsigned)rz * (unsigned)g.ny + (unsigned)ry) * (unsigned)g.nx;
-        const int4_a4 cs = *(const int4_a4 *)(g.cstart + (ok ? base + off : 0u));
+        const cs_int4 cs = cs4(g, (int64_t)(ok ? base + off : 0u));
         const int b = cs.x, e = de == 3 ? cs.w : de == 2 ? cs.z : cs.y;
         rb[q] = b;
         re[q] = b + ((e - b) & (ok ? -1 : 0));
@@ -1164,16 +1247,28 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
     const float thr_r = thr_of((float)(r2 * g.inv_cell * g.inv_cell * (1024.0 * 1024.0)) * 1.000001f);
     int k1 = KINF, k2 = KINF, k3 = KINF, k4 = KINF;   // the four smallest keys, ascending
     int ord = 0;
+    // four candidates per 16-byte gather; the distance arithmetic runs two candidates per instruction (v_pk_add / v_pk_mul /
+    // v_pk_fma_f32: 6 packed instructions per pair instead of 12 scalar ones; lane-wise IEEE, so the keys are unchanged)
+    typedef float v2f __attribute__((ext_vector_type(2)));
     auto scan4 = [&](int j0, int e, float qyr, float qzr) {
         const uint4_a4 W = *(const uint4_a4 *)(g.q10 + j0);
         const int rem = e - j0;
+        int keys[4];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const unsigned w0 = W[2 * h], w1 = W[2 * h + 1];
+            v2f cx2 = {(float)((w0 - xsub) & 4095u), (float)((w1 - xsub) & 4095u)};
+            v2f cy2 = {(float)__builtin_amdgcn_ubfe(w0, 12u, 10u), (float)__builtin_amdgcn_ubfe(w1, 12u, 10u)};
+            v2f cz2 = {(float)(w0 >> 22), (float)(w1 >> 22)};
+            const v2f qx2 = {qx, qx}, qy2 = {qyr, qyr}, qz2 = {qzr, qzr};
+            const v2f fdx = cx2 - qx2, fdy = cy2 - qy2, fdz = cz2 - qz2;
+            const v2f f = __builtin_elementwise_fma(fdz, fdz, __builtin_elementwise_fma(fdy, fdy, fdx * fdx));
+            keys[2 * h] = (__float_as_int(f.x) & ~1023) | (ord + 2 * h);
+            keys[2 * h + 1] = (__float_as_int(f.y) & ~1023) | (ord + 2 * h + 1);
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const unsigned w = W[u];
-            const float fdx = (float)((w - xsub) & 4095u) - qx, fdy = (float)((w >> 12) & 1023u) - qyr, fdz = (float)(w >> 22) - qzr;
-            const float f = __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx));
-            int key = (__float_as_int(f) & ~1023) | (ord + u);
-            key = u < rem ? key : KINF;
+            const int key = u < rem ? keys[u] : KINF;
             k4 = med3_i32(k3, k4, key);
             k3 = med3_i32(k2, k3, key);
             k2 = med3_i32(k1, k2, key);
@@ -1466,7 +1561,7 @@ __global__ void __launch_bounds__(64) k_icp_eval_t(GridView g, const double *__r
             for (int e = lane; e < nrows * (bw + 1); e += 64) {
                 const int r = e / (bw + 1), c = e - r * (bw + 1);
                 const int z = bz0 + r / bh, y = by0 + r % bh;
-                lcs[r * TL_CSP + c] = g.cstart[((int64_t)z * g.ny + y) * g.nx + bx0 + c];
+                lcs[r * TL_CSP + c] = cs1(g, ((int64_t)z * g.ny + y) * g.nx + bx0 + c);
             }
             __syncthreads();
             const int len = lane < nrows ? lcs[lane * TL_CSP + bw] - lcs[lane * TL_CSP] : 0;
@@ -1732,14 +1827,14 @@ int cloud_bbox(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, doubl
 }
 
 // exclusive scan of n ints / packed 64-bit counters on the ctx stream (k_scan_sums + k_scan_apply)
-template <class T>
+template <class T, bool MAXOP = false>
 int dev_exclusive_scan(r3d_ctx *ctx, DevArena &ar, const T *in, T *out, int64_t n, int *lo_out = nullptr, int *hi_max = nullptr) {
     if (n <= 0) return R3D_OK;
     const int tiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
     T *part = (T *)ar.get((size_t)tiles * sizeof(T));
     if (ar.rc) return ar.rc;
-    k_scan_sums<T><<<tiles, SCAN_T, 0, ctx->stream>>>(in, n, part);
-    k_scan_apply<T><<<tiles, SCAN_T, 0, ctx->stream>>>(in, n, part, out, lo_out, hi_max);
+    k_scan_sums<T, MAXOP><<<tiles, SCAN_T, 0, ctx->stream>>>(in, n, part);
+    k_scan_apply<T, MAXOP><<<tiles, SCAN_T, 0, ctx->stream>>>(in, n, part, out, lo_out, hi_max);
     R3D_HIP(ctx, hipGetLastError());
     return R3D_OK;
 }
@@ -1863,7 +1958,7 @@ int sort_by_cell(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, con
 
 // Builds the search grid.  cell_hint: minimum useful cell (search radius, or <= 0 for pure kNN); the cell is
 // refined so that occupied cells hold about `target_occ` points, and coarsened to keep the dense table <= 2^26 cells.
-int grid_build(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, double cell_hint, double target_occ, Grid &G) {
+int grid_build(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, double cell_hint, double target_occ, Grid &G, bool dense_table = false) {
     if (n <= 0) return r3d_fail(ctx, R3D_E_BADARG, "grid: empty cloud");
     if (n > 0x7fffffff) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "grid: more than 2^31-1 points");
     int rc = cloud_bbox(ctx, ar, d_pts, n, G.mn, G.mx);
@@ -1895,20 +1990,44 @@ int grid_build(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, doubl
     if (ar.rc) return ar.rc;
     rc = sort_by_cell(ctx, ar, d_pts, n, G.mn, cell, dims, 0, &G.keys, &G.keys32, &idx, sorted);   // writes the cell-sorted copy as well
     if (rc) return rc;
-    int *cnt = (int *)ar.get((size_t)(G.ncells + 1) * 4), *rs = (int *)ar.get((size_t)(G.ncells + 1) * 4);
-    int *cs = (int *)ar.get((size_t)(G.ncells + 1 + 4) * 4);   // + 4: nn_block_global reads 16 bytes at a run's first cell
-    if (ar.rc) return ar.rc;
-    R3D_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)(G.ncells + 1) * 4, ctx->stream));
-    const int nb = (int)((n + 255) / 256);
-    if (G.keys32) {
-        k_cell_counts<unsigned><<<nb, 256, 0, ctx->stream>>>((const unsigned *)G.keys, n, rs, cnt);
-        k_cell_counts2<unsigned><<<nb, 256, 0, ctx->stream>>>((const unsigned *)G.keys, n, rs, cnt);
-    } else {
-        k_cell_counts<unsigned long long><<<nb, 256, 0, ctx->stream>>>((const unsigned long long *)G.keys, n, rs, cnt);
-        k_cell_counts2<unsigned long long><<<nb, 256, 0, ctx->stream>>>((const unsigned long long *)G.keys, n, rs, cnt);
+    // R3D_CELL_TABLE = dense | lines overrides the caller's choice (A/B)
+    static const int table_env = [] { const char *e = getenv("R3D_CELL_TABLE"); return !e ? -1 : !strcmp(e, "dense") ? 1 : !strcmp(e, "lines") ? 0 : -1; }();
+    if (table_env >= 0) dense_table = table_env == 1;
+    if (dense_table) {
+        int *cnt = (int *)ar.get((size_t)(G.ncells + 1) * 4), *rs = (int *)ar.get((size_t)(G.ncells + 1) * 4);
+        int *cs = (int *)ar.get((size_t)(G.ncells + 1 + 4) * 4);   // + 4: the search reads 16 bytes at a run's first cell
+        if (ar.rc) return ar.rc;
+        R3D_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)(G.ncells + 1) * 4, ctx->stream));
+        const int nbd = (int)((n + 255) / 256);
+        if (G.keys32) {
+            k_cell_counts<unsigned><<<nbd, 256, 0, ctx->stream>>>((const unsigned *)G.keys, n, rs, cnt);
+            k_cell_counts2<unsigned><<<nbd, 256, 0, ctx->stream>>>((const unsigned *)G.keys, n, rs, cnt);
+        } else {
+            k_cell_counts<unsigned long long><<<nbd, 256, 0, ctx->stream>>>((const unsigned long long *)G.keys, n, rs, cnt);
+            k_cell_counts2<unsigned long long><<<nbd, 256, 0, ctx->stream>>>((const unsigned long long *)G.keys, n, rs, cnt);
+        }
+        if ((rc = dev_exclusive_scan<int>(ctx, ar, cnt, cs, G.ncells + 1))) return rc;
+        G.v = GridView{G.mn[0], G.mn[1], G.mn[2], cell, 1.0 / cell, dims[0], dims[1], dims[2], nullptr, nullptr, cs, sorted, idx, nullptr, nullptr, nullptr, 0.f, nullptr};
+        return R3D_OK;
     }
-    if ((rc = dev_exclusive_scan<int>(ctx, ar, cnt, cs, G.ncells + 1))) return rc;
-    G.v = GridView{G.mn[0], G.mn[1], G.mn[2], cell, 1.0 / cell, dims[0], dims[1], dims[2], cs, sorted, idx, nullptr, nullptr, nullptr, 0.f, nullptr};
+    // two-level cell table from the sorted keys (GridView::l1 / l2); sized for the worst case, only materialised lines are touched
+    const int64_t nl = ((G.ncells + CL_STRIDE) >> CL_SHIFT) + 1;
+    const int64_t max_lines = std::min<int64_t>(nl, 2 * n + 1);
+    int *mark = (int *)ar.get((size_t)nl * 4 * 2), *last1 = mark + nl;      // one fill zeroes both
+    int *ids = (int *)ar.get((size_t)nl * 4), *before = (int *)ar.get((size_t)nl * 4), *l1 = (int *)ar.get((size_t)nl * 4);
+    int *l2 = (int *)ar.get((size_t)(max_lines + 1) * CL_STRIDE * 4);
+    if (ar.rc) return ar.rc;
+    R3D_HIP(ctx, hipMemsetAsync(mark, 0, (size_t)nl * 4 * 2, ctx->stream));
+    const int nb = (int)((n + 255) / 256), nlb = (int)((nl + 255) / 256);
+    if (G.keys32) k_line_mark<unsigned><<<nb, 256, 0, ctx->stream>>>((const unsigned *)G.keys, n, mark, last1);
+    else k_line_mark<unsigned long long><<<nb, 256, 0, ctx->stream>>>((const unsigned long long *)G.keys, n, mark, last1);
+    if ((rc = dev_exclusive_scan<int>(ctx, ar, mark, ids, nl))) return rc;
+    if ((rc = dev_exclusive_scan<int, true>(ctx, ar, last1, before, nl))) return rc;
+    k_line_l1<<<nlb, 256, 0, ctx->stream>>>(mark, ids, before, nl, l1);
+    if (G.keys32) k_line_fill<unsigned><<<(unsigned)((n + 256) / 256), 256, 0, ctx->stream>>>((const unsigned *)G.keys, n, l1, nl, l2);
+    else k_line_fill<unsigned long long><<<(unsigned)((n + 256) / 256), 256, 0, ctx->stream>>>((const unsigned long long *)G.keys, n, l1, nl, l2);
+    R3D_HIP(ctx, hipGetLastError());
+    G.v = GridView{G.mn[0], G.mn[1], G.mn[2], cell, 1.0 / cell, dims[0], dims[1], dims[2], l1, l2, nullptr, sorted, idx, nullptr, nullptr, nullptr, 0.f, nullptr};
     return R3D_OK;
 }
 
@@ -2085,6 +2204,9 @@ __global__ void __launch_bounds__(1024) k_icp_step(const double *__restrict__ pa
     __syncthreads();
     if (threadIdx.x != 0) return;
     const int k = st->evals;
+    const unsigned long long now = wall_clock64();
+    if (k == 0) st->t_first = now;
+    st->t_last = now;
     const double fit = sums[0] / (double)ns, rmse = sums[0] > 0 ? sqrt(sums[1] / sums[0]) : 0.0;
     int stop = 0;
     if (k >= 1 && fabs(st->fit - fit) < rel_fit && fabs(st->rmse - rmse) < rel_rmse) { st->converged = 1; st->iterations = k; stop = 1; }
@@ -2273,7 +2395,7 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
     Grid G;
     double occ = 3.0;   // points per occupied cell the search grid aims at (R3D_ICP_OCC: A/B)
     if (const char *oe = getenv("R3D_ICP_OCC")) { const double v = atof(oe); if (v >= 0.5 && v <= 64) occ = v; }
-    if ((rc = grid_build(ctx, ar, d_t, nt, p->max_correspondence_distance, occ, G))) return rc;
+    if ((rc = grid_build(ctx, ar, d_t, nt, p->max_correspondence_distance, occ, G, true))) return rc;   // dense table: one load per row in the loop
     // float32 copy for the two-stage search (R3D_ICP_IMPL=exact: all-float64 search, for A/B).  fe = 2 x bound on
     // |float distance - exact distance|: both end points are rounded to float (relative 2^-24 per coordinate), times a
     // safety factor of 2; skipped (exact search) when the coordinates are so large that the margin stops filtering.
@@ -2428,6 +2550,16 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
         const auto t_end = std::chrono::steady_clock::now();
         stats->setup_ms = std::chrono::duration<double, std::milli>(t_loop - t_begin).count();
         stats->loop_ms = std::chrono::duration<double, std::milli>(t_end - t_loop).count();
+    }
+    {
+        static const bool dbg = [] { const char *e = getenv("R3D_ICP_DEBUG"); return e && *e == '1'; }();
+        if (dbg) {
+            const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count();
+            const double dev_ms = (double)(hst->t_last - hst->t_first) * 1e-5;   // 100 MHz ticks, first step to last step
+            if (host_ms > 5.0 + 3.0 * dev_ms)
+                fprintf(stderr, "[r3d icp] loop: host %.3f ms, device first-to-last step %.3f ms (%d evaluations): the device %s\n", host_ms, dev_ms,
+                        hst->evals, dev_ms > 0.5 * host_ms ? "itself was stalled" : "finished on time, the completion reached the host late");
+        }
     }
     return R3D_OK;
 }

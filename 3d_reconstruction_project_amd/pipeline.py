@@ -202,7 +202,8 @@ def views_to_cloud_tensors(pairs, d_disps, width, height, Q, matcher, outs, clou
     res = []
     try:
         with distributed.shared_stream(ctx) as sa:
-            sb = torch.cuda.Stream(device=dev)
+            import os
+            sb = torch.cuda.Stream(device=dev, priority=-1 if os.environ.get("R3D_CLOUD_PRIO") == "1" else 0)
             sb.wait_stream(sa)
             prev_b = cloud_ctx.get_stream()
             cloud_ctx.set_stream(sb.cuda_stream)

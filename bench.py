@@ -255,7 +255,7 @@ def bench_c5(r3d, ctx, rank, world, n_views=8, reps=3):
                 local = {}
                 err = True
                 try:
-                    if len(views) > 1:
+                    if len(views) > 1 and os.environ.get("R3D_C5_SEQ") != "1":
                         got = r3d.pipeline.views_to_cloud_tensors([(imgs[v][0].data_ptr(), imgs[v][1].data_ptr()) for v in views],
                                                                   [d.data_ptr() for d in d_disps], W, H, Q, m, [bufs[v] for v in views],
                                                                   cloud_ctx, voxel=0.01, max_nn=30, max_depth=3.0,
