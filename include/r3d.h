@@ -141,8 +141,12 @@ int r3d_voxel_downsample_tensor(r3d_ctx *ctx, const double *xyz, const double *c
 /* replaces: pcd.estimate_normals(KDTreeSearchParamHybrid(radius, max_nn))   pointcloud_alignment.py:27-28,
  * test/GICP1.py:77,95,97,148; tensor estimate_normals(max_nn, radius)   normal_estimation.py:20.
  * radius <= 0 selects KDTreeSearchParamKNN(max_nn).  <= max_nn nearest neighbours with distance < radius (query
- * included), population covariance, unit eigenvector of the smallest eigenvalue; fewer than 3 neighbours -> (0,0,1).
- * prev_normals (may be NULL): when given, each normal is flipped to agree with it (legacy behaviour). */
+ * included, nearest first); covariance and normal as legacy Open3D computes them -- one pass of nine cumulants over the raw
+ * coordinates, then FastEigen3x3 (closed form), with the fused multiply-adds of the build that recorded the reference's frames:
+ * the normals of those frames are reproduced SIGN INCLUDED to <= 5e-12 (oracle/normals.c has the derivation); the sign is the
+ * one the closed form produces.  Fewer than 3 neighbours (or an all-zero covariance) -> (0,0,1).
+ * prev_normals (may be NULL): when given, each normal is flipped to agree with it and a degenerate one keeps it (legacy
+ * behaviour of a cloud that already carries normals). */
 int r3d_estimate_normals(r3d_ctx *ctx, const double *xyz, int64_t n, double radius, int32_t max_nn, const double *prev_normals,
                          double *normals);
 
