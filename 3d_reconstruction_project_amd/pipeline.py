@@ -190,36 +190,53 @@ def views_to_cloud_tensors(pairs, d_disps, width, height, Q, matcher, outs, clou
     """Several views owned by ONE GPU (a rank that holds more than one view of the C5 batch): the same results as one
     view_to_cloud_tensors call per view, but the SGM maps go through the matcher's batch entry point (three maps in flight on
     the library's lanes, r3d_sgbm_compute_batch_events_dev) and the cloud stages of view i (reprojection -> voxel grid ->
-    normals, on `cloud_ctx`, a second Context with its own stream and arena) start on map i's completion event, underneath the
-    SGM kernels of the later views.  pairs: [(d_left, d_right)] device pointers; d_disps: one int16 device buffer PER view;
-    outs: one [2, capacity, 3] float64 tensor per view.  Returns [out_i[:, :n_i]]."""
+    normals) start on map i's completion event, underneath the SGM kernels of the later views, on `cloud_ctx`: a second Context
+    with its own stream and arena, or a LIST of them -- the cloud stages are a chain of small kernels with host round trips in
+    between, so each extra context gets its own host thread (ctypes releases the GIL) and the chains of different views overlap.
+    pairs: [(d_left, d_right)] device pointers; d_disps: one int16 device buffer PER view; outs: one [2, capacity, 3] float64
+    tensor per view.  Returns [out_i[:, :n_i]]."""
     import torch
     ctx = matcher.context
     n = len(pairs)
-    assert len(d_disps) == n and len(outs) == n and cloud_ctx is not ctx
+    cctxs = list(cloud_ctx) if isinstance(cloud_ctx, (list, tuple)) else [cloud_ctx]
+    assert len(d_disps) == n and len(outs) == n and all(c is not ctx for c in cctxs) and len({id(c) for c in cctxs}) == len(cctxs)
     dev = outs[0].device
     evs = [ctx.event() for _ in range(n)]
-    res = []
+    res = [None] * n
     try:
         with distributed.shared_stream(ctx) as sa:
             import os
-            sb = torch.cuda.Stream(device=dev, priority=-1 if os.environ.get("R3D_CLOUD_PRIO") == "1" else 0)
-            sb.wait_stream(sa)
-            prev_b = cloud_ctx.get_stream()
-            cloud_ctx.set_stream(sb.cuda_stream)
+            prio = -1 if os.environ.get("R3D_CLOUD_PRIO") == "1" else 0
+            sbs = [torch.cuda.Stream(device=dev, priority=prio) for _ in cctxs]
+            prev = [c.get_stream() for c in cctxs]
+            for c, sb in zip(cctxs, sbs):
+                sb.wait_stream(sa)
+                c.set_stream(sb.cuda_stream)
             try:
                 matcher.compute_batch_device([p[0] for p in pairs], [p[1] for p in pairs], width, height, width, list(d_disps),
                                              done_events=evs)
-                for i in range(n):
-                    cloud_ctx.wait_event(evs[i])
-                    k = cloud_ops.disparity_to_cloud_resident(d_disps[i], width, height, Q, outs[i][0].data_ptr(), outs[i][1].data_ptr(),
-                                                              outs[i].shape[1], matcher.getMinDisparity(), max_depth,
-                                                              None if poses is None else poses[i], voxel, normal_radius or 2 * voxel,
-                                                              max_nn, ctx=cloud_ctx)
-                    res.append(outs[i][:, :k])
-                sa.wait_stream(sb)
+
+                def chain(w):
+                    c = cctxs[w]
+                    for i in range(w, n, len(cctxs)):
+                        c.wait_event(evs[i])
+                        k = cloud_ops.disparity_to_cloud_resident(d_disps[i], width, height, Q, outs[i][0].data_ptr(), outs[i][1].data_ptr(),
+                                                                  outs[i].shape[1], matcher.getMinDisparity(), max_depth,
+                                                                  None if poses is None else poses[i], voxel, normal_radius or 2 * voxel,
+                                                                  max_nn, ctx=c)
+                        res[i] = outs[i][:, :k]
+                if len(cctxs) == 1:
+                    chain(0)
+                else:
+                    from concurrent.futures import ThreadPoolExecutor
+                    with ThreadPoolExecutor(len(cctxs)) as pool:
+                        for f in [pool.submit(chain, w) for w in range(len(cctxs))]:
+                            f.result()                       # re-raises a worker's exception here
+                for sb in sbs:
+                    sa.wait_stream(sb)
             finally:
-                cloud_ctx.set_stream(prev_b)
+                for c, p in zip(cctxs, prev):
+                    c.set_stream(p)
     finally:
         ctx.sync()
         for e in evs:
@@ -236,7 +253,10 @@ def multi_view_fuse_tensors(local, n_views, threshold=0.02, mode=cloud_ops.GICP,
     [2, N, 3] tensor, which every rank ends up holding (rank 0 hands it to the mesher, mesh_reconstruction.py:22-37).
     Returns (fused tensor, {view_id: T}).  `register(src [2,n,3], tgt [2,m,3]) -> 4x4` and `transform(block, T) -> block`
     replace the HIP calls in the CPU (gloo) tests; with device tensors and no stubs the HIP library does the work.
-    timings (dict, optional) receives exchange_ms / register_ms / fuse_ms measured with events on the shared stream."""
+    timings (dict, optional) receives exchange_ms / register_ms / fuse_ms measured with events on the shared stream.
+    (A rank that owns several views registers them one after the other: running them on several contexts / host threads at
+    once was measured -- 7 registrations of 109 k-point clouds: 2.8 ms sequential, 3.3-3.8 ms on two contexts, 2.5-3.0 ms on
+    four -- and dropped.)"""
     import torch
     dev = distributed.exchange_device()
     on_gpu = dev.type == "cuda"
@@ -280,22 +300,23 @@ def _multi_view_fuse_on_stream(local, n_views, threshold, mode, max_iteration, r
     t1 = mark()
     ref = everyone[0]
     mine = {}
-    for v in local:
+
+    def register_view(v, c):
         # a registration that fails on this rank must not strand the others in the next collective: the exception travels as
         # a flag through gather_transforms, which then raises on every rank together
         try:
             if v == 0:
-                T = np.eye(4)
-            elif register is not None:
-                T = np.asarray(register(everyone[v], ref), dtype=np.float64)
-            else:
-                src = everyone[v]
-                T = cloud_ops.registration_device(src[0].data_ptr(), src.shape[1], ref[0].data_ptr(), ref.shape[1], threshold,
-                                                  mode=mode, max_iteration=max_iteration, d_source_normals=src[1].data_ptr(),
-                                                  d_target_normals=ref[1].data_ptr(), ctx=ctx)["T"]
+                return np.eye(4)
+            if register is not None:
+                return np.asarray(register(everyone[v], ref), dtype=np.float64)
+            src = everyone[v]
+            return cloud_ops.registration_device(src[0].data_ptr(), src.shape[1], ref[0].data_ptr(), ref.shape[1], threshold,
+                                                 mode=mode, max_iteration=max_iteration, d_source_normals=src[1].data_ptr(),
+                                                 d_target_normals=ref[1].data_ptr(), ctx=c)["T"]
         except Exception as e:  # noqa: BLE001
-            T = e
-        mine[v] = T
+            return e
+    for v in local:
+        mine[v] = register_view(v, ctx)
     t2 = mark()
     Ts = distributed.gather_transforms(mine, n_views)
     total = sum(everyone[v].shape[1] for v in range(n_views))

@@ -239,7 +239,8 @@ def bench_c5(r3d, ctx, rank, world, n_views=8, reps=3):
                 d_disps = [torch.empty(W * H, dtype=torch.int16, device="cuda") for _ in views]
                 bufs = {v: torch.empty((2, cap, 3), dtype=torch.float64, device="cuda") for v in views}
                 if len(views) > 1:
-                    cloud_ctx = r3d.Context(ctx.device)
+                    ncc = max(1, min(int(os.environ.get("R3D_C5_CLOUD_CTX", "3")), 4))
+                    cloud_ctx = [r3d.Context(ctx.device) for _ in range(ncc)]
             except Exception as e:  # noqa: BLE001
                 err = e
             Dm.agree(err, "C5 input set-up")
@@ -297,8 +298,9 @@ def bench_c5(r3d, ctx, rank, world, n_views=8, reps=3):
                                "normals k30) resident in HBM -> all-gather-v (RCCL, device tensors) -> GICP of every view to view 0 -> "
                                "all-gather of the 4x4s -> fused cloud on every rank",
                    "n_views": n_views, "views_per_rank": len(views),
-                   "view_chain": ("3 SGM maps in flight (r3d_sgbm_compute_batch_events_dev), cloud stages of view i on a second context "
-                                  "underneath the SGM kernels of views i+1.." if len(views) > 1 else "one view per rank: SGM then cloud stages, one stream"),
+                   "view_chain": ("3 SGM maps in flight (r3d_sgbm_compute_batch_events_dev), cloud stages of view i on %d further context(s) "
+                                  "(own stream, arena and host thread each) underneath the SGM kernels of views i+1.." % len(cloud_ctx)
+                                  if len(views) > 1 else "one view per rank: SGM then cloud stages, one stream"),
                    "view_ms": round(float(st[0]), 3), "exchange_ms": round(float(st[1]), 3),
                    "register_ms": round(float(st[2]), 3), "fuse_ms": round(float(st[3]), 3), "batch_ms": round(float(st[4]), 3),
                    "views_per_s": round(1e3 * n_views / float(st[4]), 2), "fused_points": int(fused.shape[1]),
@@ -319,8 +321,8 @@ def bench_c5(r3d, ctx, rank, world, n_views=8, reps=3):
                 os.remove(path)
         finally:
             torch.cuda.synchronize()
-            if cloud_ctx is not None:
-                cloud_ctx.close()
+            for c in (cloud_ctx or []):
+                c.close()
     return out
 
 

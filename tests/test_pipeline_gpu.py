@@ -256,14 +256,15 @@ def c5_views(r3d, synth):
         buf = torch.empty((2, cap, 3), dtype=torch.float64, device="cuda")
         seq[v] = r3d.pipeline.view_to_cloud_tensors(imgs[v][2].data_ptr(), imgs[v][3].data_ptr(), d_disp.data_ptr(), C5_W, C5_H, Q, m, buf,
                                                     voxel=0.01, max_nn=30, max_depth=3.0, pose=np.linalg.inv(_c5_pose(synth, v)))
-    ctx2 = r3d.Context(m.context.device)
+    ctx2 = [r3d.Context(m.context.device), r3d.Context(m.context.device)]     # two cloud contexts: one host thread each
     disps = [torch.empty(C5_W * C5_H, dtype=torch.int16, device="cuda") for _ in (0, 1)]
     bufs = [torch.empty((2, cap, 3), dtype=torch.float64, device="cuda") for _ in (0, 1)]
     piped = r3d.pipeline.views_to_cloud_tensors([(imgs[v][2].data_ptr(), imgs[v][3].data_ptr()) for v in (0, 1)], [d.data_ptr() for d in disps],
                                                 C5_W, C5_H, Q, m, bufs, ctx2, voxel=0.01, max_nn=30, max_depth=3.0,
                                                 poses=[np.linalg.inv(_c5_pose(synth, v)) for v in (0, 1)])
     torch.cuda.synchronize()
-    ctx2.close()
+    for c in ctx2:
+        c.close()
     return dict(Q=Q, imgs=imgs, seq=seq, piped=piped)
 
 
