@@ -5,6 +5,13 @@ import os
 
 import numpy as np
 
+# HIP maps streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4), in order per queue.  The library pipelines maps over
+# three lanes (own stream each) next to the context stream(s) and the caller's streams: with four queues two of them share one and
+# their kernels serialise -- measured at C2 with three maps in flight: 338-340 maps/s with 4 queues, 365-370 with 8 (16: the same);
+# the 8-view batch on one GPU 31.2-31.6 -> 29.4-29.9 ms.  Read by the HIP runtime when it initialises, i.e. at the first GPU call of
+# the process: set here, at import, unless the user has chosen a value.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libr3d_hip.so")
 
