@@ -283,7 +283,9 @@ int r3d_sgbm_compute_batch_events_dev(r3d_ctx *ctx, const r3d_sgbm_params *p, in
     if (n < 0 || (n > 0 && (!d_left || !d_right || !d_disp))) return r3d_fail(ctx, R3D_E_BADARG, "sgbm batch: bad argument");
     if (n == 0) return R3D_OK;
     R3D_HIP(ctx, hipSetDevice(ctx->device));
-    const int lanes = n < R3D_SGM_LANES ? n : R3D_SGM_LANES;
+    // maps in flight: R3D_SGM_LANES (default 3; measured A/B values 2 .. 6)
+    static const int max_lanes = [] { const char *e = getenv("R3D_SGM_LANES"); const int v = e ? atoi(e) : R3D_SGM_LANES; return v < 1 ? 1 : (v > R3D_SGM_MAX_LANES ? R3D_SGM_MAX_LANES : v); }();
+    const int lanes = n < max_lanes ? n : max_lanes;
     if (!ctx->fork_ev) R3D_HIP(ctx, hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
     for (int l = 0; l < lanes; l++) {
         r3d_sgm_ws &ws = ctx->ws[l];

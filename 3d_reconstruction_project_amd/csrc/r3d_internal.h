@@ -26,6 +26,7 @@ struct r3d_prof_set {
     bool pending = false;
 };
 
+#define R3D_SGM_MAX_LANES 6   /* workspaces that can exist; r3d_sgbm_compute_batch* uses R3D_SGM_LANES of them (env, default 3) */
 #define R3D_SGM_LANES 3
 #define R3D_SGM_SLABS 8   // most column slabs of the cost / forward-scan overlap (sgm.hip)
 
@@ -55,7 +56,7 @@ struct r3d_ctx {
     bool poisoned = false;
     // grow-only workspace
     r3d_buf img_l, img_r, out;
-    r3d_sgm_ws ws[R3D_SGM_LANES];
+    r3d_sgm_ws ws[R3D_SGM_MAX_LANES];
     hipEvent_t fork_ev = nullptr;
     // geometry of the last sgbm call (for debug fetch)
     int last_w = 0, last_h = 0, last_w1 = 0, last_dp = 0, last_impl = 0;

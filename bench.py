@@ -523,19 +523,20 @@ def main():
     # library's lanes, so the cost / hscan / vscan kernels of consecutive maps overlap.  Whole-job figure = sum over ranks.
     piped = None
     if lanes == 1 and not args.no_extras:
-        outs = [dD] + [ctx.alloc(W * H * 2) for _ in range(2)]
-        nb = max(6, 3 * ((args.steps + 2) // 3))
-        m.compute_batch_device([dL] * 3, [dR] * 3, W, H, W, outs)            # lanes 1-2 allocate at first use
+        nl = max(1, min(int(os.environ.get("R3D_SGM_LANES", "3")), 6))           # the library reads the same variable
+        outs = [dD] + [ctx.alloc(W * H * 2) for _ in range(nl - 1)]
+        nb = max(2 * nl, nl * ((args.steps + nl - 1) // nl))
+        m.compute_batch_device([dL] * nl, [dR] * nl, W, H, W, outs)            # the other lanes allocate at first use
         barrier()
         tp0 = time.perf_counter()
-        m.compute_batch_device([dL] * nb, [dR] * nb, W, H, W, [outs[i % 3] for i in range(nb)])
+        m.compute_batch_device([dL] * nb, [dR] * nb, W, H, W, [outs[i % nl] for i in range(nb)])
         barrier()
         pdt = time.perf_counter() - tp0
         if dist is not None:
             t = torch.tensor([pdt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             pdt = float(t.item())
-        piped = {"maps_in_flight": 3, "maps": nb * world, "value": round(world * nb / pdt, 2), "unit": "disparity-maps/s",
+        piped = {"maps_in_flight": nl, "maps": nb * world, "value": round(world * nb / pdt, 2), "unit": "disparity-maps/s",
                  "ms_per_map": round(1e3 * pdt / nb, 4),
                  "pipeline_frac": round(ALG_BYTES["map"] * nb / pdt / HBM_PEAK, 4),
                  "entry_point": "r3d_sgbm_compute_batch_dev", "n_gpus": world}
