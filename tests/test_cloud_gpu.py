@@ -648,3 +648,32 @@ def test_counting_sort_is_the_stable_key_index_order(r3d, case):
         idx, keys = r3d.cloud_ops.debug_sort_by_cell(p, org, cell, dims, order, impl)
         np.testing.assert_array_equal(idx, want)
         np.testing.assert_array_equal(keys.astype(np.int64), want_keys[want])
+
+
+def test_normals_on_degenerate_neighbourhoods_follow_the_closed_form(r3d):
+    """The branches of FastEigen3x3 that scanned surfaces rarely take, kernel against oracle (same formulas, same fused
+    multiply-adds): exactly planar lattices (a zero eigenvalue, two equal ones), axis-aligned point sets whose covariance is
+    exactly diagonal (the `norm == 0` branch picks an axis), coincident points (zero covariance -> (0,0,1)), fewer than three
+    neighbours, and collinear points (the normal is any unit vector orthogonal to the line: only that is asserted)."""
+    g = np.arange(12) * 0.01
+    plane = np.stack(np.meshgrid(g, g, [0.25]), -1).reshape(-1, 3)                           # lattice in z = 0.25
+    n = r3d.cloud_ops.estimate_normals(plane, 0.025, 30)
+    w = co.estimate_normals_hybrid(plane, 0.025, 30)
+    assert np.abs(np.abs(n[:, 2]) - 1).max() < 1e-9 and np.abs(n - w).max() < 1e-9
+    tilted = plane @ np.array([[0.8, 0, 0.6], [0, 1, 0], [-0.6, 0, 0.8]]).T               # the same lattice on a tilted plane
+    n, w = r3d.cloud_ops.estimate_normals(tilted, 0.025, 30), co.estimate_normals_hybrid(tilted, 0.025, 30)
+    assert np.abs(n - w).max() < 1e-7 and np.abs(np.abs(n @ np.array([0.6, 0, 0.8])) - 1).max() < 1e-7
+    cross = np.array([[0, 0, 0], [0.01, 0, 0], [-0.01, 0, 0], [0, 0.02, 0], [0, -0.02, 0], [0, 0, 0.005], [0, 0, -0.005]])
+    n, w = r3d.cloud_ops.estimate_normals(cross, 1.0, 30), co.estimate_normals_hybrid(cross, 1.0, 30)   # exactly diagonal covariance
+    np.testing.assert_array_equal(n, w)
+    np.testing.assert_array_equal(n[0], [0, 0, 1])                                           # smallest spread along z
+    same = np.concatenate([np.tile([[0.3, 0.2, 0.1]], (6, 1)), [[5.0, 5, 5], [5.001, 5, 5]]])
+    n, w = r3d.cloud_ops.estimate_normals(same, 0.05, 30), co.estimate_normals_hybrid(same, 0.05, 30)
+    np.testing.assert_array_equal(n, w)
+    assert (n == [0, 0, 1]).all()                                                            # zero covariance / fewer than 3 neighbours
+    prev = np.tile([[0.0, 1.0, 0.0]], (len(same), 1))
+    np.testing.assert_array_equal(r3d.cloud_ops.estimate_normals(same, 0.05, 30, prev_normals=prev), prev)   # a cloud with normals keeps them
+    line = np.stack([np.linspace(0, 0.05, 9), np.linspace(0, 0.1, 9) * 0.5, np.zeros(9)], 1)
+    n = r3d.cloud_ops.estimate_normals(line, 1.0, 30)
+    d = (line[-1] - line[0]) / np.linalg.norm(line[-1] - line[0])
+    assert np.abs(np.linalg.norm(n, axis=1) - 1).max() < 1e-9 and np.abs(n @ d).max() < 1e-6

@@ -1,5 +1,5 @@
 #!/bin/bash
-# AddressSanitizer + UndefinedBehaviourSanitizer run of the oracle's C code (oracle/sgbm3way.c, oracle/graph.c) on the CPU:
+# AddressSanitizer + UndefinedBehaviourSanitizer run of the oracle's C code (oracle/sgbm3way.c, oracle/graph.c, oracle/normals.c) on the CPU:
 # the sanitizers are not available for GPU code on this pool, and the C restatement is what every disparity map is judged
 # against.  Builds an instrumented copy under /tmp and drives it through the normal Python front ends over sizes that hit the
 # stripe / border / speckle / negative-minDisparity / D = 256 paths and the Kruskal helper.  Usage: tools/cpu_sanitize_oracle.sh
@@ -7,7 +7,7 @@ set -euo pipefail
 root="$(cd "$(dirname "$0")/.." && pwd)"
 tmp="$(mktemp -d /tmp/r3d_asan.XXXXXX)"
 gcc -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fopenmp -fPIC -std=c11 -shared -o "$tmp/libr3d_oracle.so" \
-    "$root/oracle/sgbm3way.c" "$root/oracle/graph.c" -lm
+    "$root/oracle/sgbm3way.c" "$root/oracle/graph.c" "$root/oracle/normals.c" -ffp-contract=off -lm
 cat > "$tmp/run.py" <<PY
 import importlib, sys
 sys.path.insert(0, "$root")
@@ -31,7 +31,11 @@ co.kruskal(5, np.array([0, 1, 2, 3, 0]), np.array([1, 2, 3, 4, 4]), np.array([1.
 rng = np.random.default_rng(0)
 p3 = rng.random((500, 3)); nn = rng.standard_normal((500, 3)); nn /= np.linalg.norm(nn, axis=1, keepdims=True)
 co.orient_normals(p3, nn, 8)
-print("sanitized oracle calls:", n + 2, "- no report")
+# cumulant covariance + FastEigen3x3 (normals.c): ragged neighbour lists incl. < 3 neighbours, degenerate and zero covariances
+co.estimate_normals_hybrid(p3, 0.15, 12)
+co.estimate_normals_hybrid(np.concatenate([p3[:40], np.tile(p3[:1], (5, 1)), p3[:1] + 9.0]), 0.05, 30)
+co.fast_eigen3x3(np.concatenate([np.zeros((2, 3, 3)), np.eye(3)[None], np.diag([3.0, 1.0, 2.0])[None], np.ones((1, 3, 3))]))
+print("sanitized oracle calls:", n + 5, "- no report")
 PY
 ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)" python3 "$tmp/run.py"
 rm -rf "$tmp"
