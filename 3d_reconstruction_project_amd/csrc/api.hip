@@ -134,6 +134,8 @@ void r3d_destroy(r3d_ctx *ctx) {
         if (ws.stream) (void)hipStreamDestroy(ws.stream);
         if (ws.done) (void)hipEventDestroy(ws.done);
         if (ws.aux) (void)hipStreamDestroy(ws.aux);
+        if (ws.vs_fork) (void)hipEventDestroy(ws.vs_fork);
+        if (ws.vs_join) (void)hipEventDestroy(ws.vs_join);
         for (hipEvent_t e : ws.slab_ev)
             if (e) (void)hipEventDestroy(e);
     }

@@ -38,6 +38,7 @@ struct r3d_sgm_ws {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     hipStream_t aux = nullptr;                       // second stream of the lane: cost slabs ahead of the forward scan
+    hipEvent_t vs_fork = nullptr, vs_join = nullptr;   // the balanced split of the vertical scan (tail launch on `aux`)
     hipEvent_t slab_ev[R3D_SGM_SLABS + 1] = {};      // [j]: cost of slab j written; [R3D_SGM_SLABS]: fork point
     r3d_prof_set prof[R3D_PROF_SETS];
     int prof_cur = 0;

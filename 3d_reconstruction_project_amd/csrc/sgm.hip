@@ -1269,11 +1269,11 @@ __global__ void __launch_bounds__(64) k_hscan3(const int *__restrict__ cvol, con
 template <int NPL, int LPC>
 __global__ void __launch_bounds__(64) k_vscan2(const int *__restrict__ cvol, const int *__restrict__ cspec,
                                                const int *__restrict__ hvol, SgmGeom g, float inv_a, int16_t *__restrict__ raw,
-                                               int16_t *__restrict__ mins) {
+                                               int16_t *__restrict__ mins, int col0) {
     constexpr int CPW = 64 / LPC, DPW = NPL * LPC;  // columns per wave, words per column
     static_assert(NPL == 4 || NPL == 8 || NPL == 16, "one, two or four 16-byte loads per lane");
     const int lane = threadIdx.x, k = lane % LPC, grp = lane / LPC, n = blockIdx.y;
-    const int xc = blockIdx.x * CPW + grp;
+    const int xc = col0 + blockIdx.x * CPW + grp;   // col0: first cost column of this launch (the balanced split below)
     const bool col_ok = xc < g.W1;
     const size_t rowWords = (size_t)g.W1 * DPW;
     const int src_start = max(min(n * g.stripe_sz - g.overlap, g.H), 0);
@@ -1807,20 +1807,46 @@ int launch_cost2(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st,
 // SIMD carries two; needs whole 32-disparity lanes) is the default where it applies, 8 columns (NPL = 8, LPC = 8) otherwise;
 // R3D_VSCAN_COLS = 4 | 8 | 16 forces one for A/B runs (4 columns: 3136 finer-grained waves, measured 1.15 ms against 0.89 ms for 8:
 // the extra cross-lane stages cost more than the better SIMD balance returns; 16 vs 8: 0.921 vs 0.956 ms interleaved).
-int launch_vscan2(hipStream_t st, const SgmGeom &g, float inv_a, const int *cost, const int *cspec, const int *hsum, int16_t *raw,
-                  int16_t *mins) {
+// Balanced split (R3D_VSCAN_SPLIT=1; DEFAULT OFF: measured slower).  The kernel is one chain per wave, limited by what a CU's
+// memory pipeline keeps in flight, so it lasts as long as its most loaded CU: 784 single-wave workgroups at C2 are three per CU
+// on 240 CUs and FOUR on 16, and those 16 set the time (tools/gpu_balance_probe.py: 117 us per million cells with 784 waves, 108
+// with exactly 768 at W = 3200).  The split cuts the launch into a main part whose wave count is a multiple of 256 and a tail of
+// the remaining columns in the 8-column mapping (half the load per wave) running concurrently on the lane's second stream.
+// MEASURED (interleaved on one box): 0.960 ms with the split against 0.822-0.828 ms without -- a wave of the 8-column mapping
+// needs longer per row (its extra cross-lane stage), and the join waits for it; the imbalance costs less than that.
+int launch_vscan2(r3d_ctx *ctx, r3d_sgm_ws &ws, hipStream_t st, const SgmGeom &g, float inv_a, const int *cost, const int *cspec, const int *hsum,
+                  int16_t *raw, int16_t *mins) {
     static const int force = [] { const char *e = getenv("R3D_VSCAN_COLS"); return e ? atoi(e) : 0; }();
+    static const bool split_on = [] { const char *e = getenv("R3D_VSCAN_SPLIT"); return e && !strcmp(e, "1"); }();
     if (g.DP == 32) {
-        k_vscan2<4, 4><<<dim3((g.W1 + 15) / 16, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins);
+        k_vscan2<4, 4><<<dim3((g.W1 + 15) / 16, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins, 0);
     } else if (g.DP == 64) {
-        k_vscan2<8, 4><<<dim3((g.W1 + 15) / 16, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins);
+        k_vscan2<8, 4><<<dim3((g.W1 + 15) / 16, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins, 0);
     } else if (g.DP == 128) {
         const bool ok16 = g.D % 32 == 0;
-        if ((force == 16 || force == 0) && ok16) k_vscan2<16, 4><<<dim3((g.W1 + 15) / 16, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins);
-        else if (force == 4) k_vscan2<4, 16><<<dim3((g.W1 + 3) / 4, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins);
-        else k_vscan2<8, 8><<<dim3((g.W1 + 7) / 8, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins);
+        if ((force == 16 || force == 0) && ok16) {
+            const int groups = (g.W1 + 15) / 16, main_groups = (groups / 64) * 64;
+            if (split_on && main_groups >= 64 && main_groups < groups) {
+                if (!ws.aux) R3D_HIP(ctx, hipStreamCreateWithFlags(&ws.aux, hipStreamNonBlocking));
+                if (!ws.vs_fork) {
+                    R3D_HIP(ctx, hipEventCreateWithFlags(&ws.vs_fork, hipEventDisableTiming));
+                    R3D_HIP(ctx, hipEventCreateWithFlags(&ws.vs_join, hipEventDisableTiming));
+                }
+                const int col0 = main_groups * 16, tail_cols = g.W1 - col0;
+                R3D_HIP(ctx, hipEventRecord(ws.vs_fork, st));
+                R3D_HIP(ctx, hipStreamWaitEvent(ws.aux, ws.vs_fork, 0));
+                k_vscan2<8, 8><<<dim3((tail_cols + 7) / 8, 4), 64, 0, ws.aux>>>(cost, cspec, hsum, g, inv_a, raw, mins, col0);
+                R3D_HIP(ctx, hipEventRecord(ws.vs_join, ws.aux));
+                SgmGeom gm = g;
+                k_vscan2<16, 4><<<dim3(main_groups, 4), 64, 0, st>>>(cost, cspec, hsum, gm, inv_a, raw, mins, 0);
+                R3D_HIP(ctx, hipStreamWaitEvent(st, ws.vs_join, 0));
+            } else {
+                k_vscan2<16, 4><<<dim3(groups, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins, 0);
+            }
+        } else if (force == 4) k_vscan2<4, 16><<<dim3((g.W1 + 3) / 4, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins, 0);
+        else k_vscan2<8, 8><<<dim3((g.W1 + 7) / 8, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins, 0);
     } else {
-        k_vscan2<8, 16><<<dim3((g.W1 + 3) / 4, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins);
+        k_vscan2<8, 16><<<dim3((g.W1 + 3) / 4, 4), 64, 0, st>>>(cost, cspec, hsum, g, inv_a, raw, mins, 0);
     }
     return (int)hipGetLastError();
 }
@@ -2104,9 +2130,9 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
         dim3 grid((g.W1 + CPW - 1) / CPW, 4);
         if (!use_v1) {
             // mapping per disparity-slot layout: see launch_vscan2
-            if (int e = launch_vscan2(st, g, inv_a, (const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p,
+            if (int e = launch_vscan2(ctx, ws, st, g, inv_a, (const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p,
                                       (int16_t *)ws.raw.p, (int16_t *)ws.mins.p))
-                return r3d_fail(ctx, R3D_E_HIP, "k_vscan2 launch failed: %s", hipGetErrorString((hipError_t)e));
+                return e < 0 ? e : r3d_fail(ctx, R3D_E_HIP, "k_vscan2 launch failed: %s", hipGetErrorString((hipError_t)e));
         } else if (g.NP == 1) k_vscan<1, CPW><<<grid, 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
         else k_vscan<2, CPW><<<grid, 64, 0, st>>>((const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p, g, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p);
         R3D_HIP(ctx, hipGetLastError());
