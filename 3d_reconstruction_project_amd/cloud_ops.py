@@ -32,7 +32,17 @@ P2P, P2PLANE, GICP = 0, 1, 2
 
 _lib.register({
     "r3d_debug_sort_by_cell": ([_vp, _vp, ctypes.c_int64, _vp, ctypes.c_double, _vp, ctypes.c_int32, ctypes.c_int32, _vp, _vp], ctypes.c_int),
+    "r3d_debug_exclusive_scan": ([_vp, _vp, ctypes.c_int64, ctypes.c_int32, _vp], ctypes.c_int),
 })
+
+
+def debug_exclusive_scan(values, maximum=False, ctx=None):
+    """r3d_debug_exclusive_scan: exclusive prefix sum (or running maximum) of int32 values on the device."""
+    ctx = ctx or _lib.default_context()
+    v = np.ascontiguousarray(values, dtype=np.int32)
+    out = np.empty_like(v)
+    ctx.call("r3d_debug_exclusive_scan", v.ctypes.data_as(_vp), len(v), int(bool(maximum)), out.ctypes.data_as(_vp))
+    return out
 
 
 def debug_sort_by_cell(points, origin, cell, dims, key_order, impl=0, ctx=None):

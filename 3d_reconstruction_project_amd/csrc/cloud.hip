@@ -3394,3 +3394,19 @@ extern "C" int r3d_debug_sort_by_cell(r3d_ctx *ctx, const double *xyz, int64_t n
         for (int64_t i = 0; i < n; i++) keys_out[i] = k4[(size_t)i];
     return R3D_OK;
 }
+
+extern "C" int r3d_debug_exclusive_scan(r3d_ctx *ctx, const int32_t *in, int64_t n, int32_t op, int32_t *out) {
+    R3D_ROCTX_RANGE("r3d_debug_exclusive_scan");
+    if (!ctx) return R3D_E_BADARG;
+    if (!in || !out || n <= 0 || op < 0 || op > 1) return r3d_fail(ctx, R3D_E_BADARG, "debug_exclusive_scan: bad argument");
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    DevArena ar(ctx);
+    int *d_in = (int *)ar.get((size_t)n * 4), *d_out = (int *)ar.get((size_t)n * 4);
+    if (ar.rc) return ar.rc;
+    R3D_HIP(ctx, hipMemcpyAsync(d_in, in, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    const int rc = op == 1 ? dev_exclusive_scan<int, true>(ctx, ar, d_in, d_out, n) : dev_exclusive_scan<int>(ctx, ar, d_in, d_out, n);
+    if (rc) return rc;
+    R3D_HIP(ctx, hipMemcpyAsync(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return R3D_OK;
+}

@@ -52,6 +52,9 @@ int r3d_debug_streambench(r3d_ctx *ctx, int32_t mode, int32_t rows, uint64_t row
  * hand-written run-based counting sort (default path), 1: the library radix sort (fallback path).  keys_out may be NULL. */
 int r3d_debug_sort_by_cell(r3d_ctx *ctx, const double *xyz, int64_t n, const double *org3, double cell, const int32_t *dims3, int32_t key_order,
                            int32_t impl, int32_t *idx_out, uint64_t *keys_out);
+/* diagnostic: the hand-written exclusive scan (k_scan_sums + k_scan_apply) on n int32 host values; op 0 = sum, 1 = running maximum
+ * (values >= 0).  out[i] = op over in[0 .. i-1], out[0] = 0. */
+int r3d_debug_exclusive_scan(r3d_ctx *ctx, const int32_t *in, int64_t n, int32_t op, int32_t *out);
 /* checks the cross-lane primitives (DPP shifts, permlane swaps, wave reductions) the kernels rely on */
 int r3d_selftest(r3d_ctx *ctx);
 

@@ -681,3 +681,17 @@ def test_normals_on_degenerate_neighbourhoods_follow_the_closed_form(r3d):
     n = r3d.cloud_ops.estimate_normals(line, 1.0, 30)
     d = (line[-1] - line[0]) / np.linalg.norm(line[-1] - line[0])
     assert np.abs(np.linalg.norm(n, axis=1) - 1).max() < 1e-9 and np.abs(n @ d).max() < 1e-6
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 4095, 4096, 4097, 65536, 1_000_003])
+def test_hand_written_scan_matches_cumsum(r3d, n):
+    """k_scan_sums / k_scan_apply around their tile (4096) and vector (16) boundaries, sum and running maximum."""
+    rng = np.random.default_rng(n)
+    v = rng.integers(0, 50, n).astype(np.int32)
+    got = r3d.cloud_ops.debug_exclusive_scan(v)
+    want = np.concatenate([[0], np.cumsum(v[:-1], dtype=np.int64)]).astype(np.int32)
+    np.testing.assert_array_equal(got, want)
+    w = (rng.integers(0, 1000, n) * (rng.random(n) < 0.1)).astype(np.int32)            # mostly zeros, like the per-line "last slot" table
+    gotm = r3d.cloud_ops.debug_exclusive_scan(w, maximum=True)
+    wantm = np.concatenate([[0], np.maximum.accumulate(w[:-1])]).astype(np.int32) if n > 1 else np.zeros(1, np.int32)
+    np.testing.assert_array_equal(gotm, wantm)
