@@ -297,7 +297,11 @@ def test_c5_exchange_and_registration_under_rccl_equal_the_oracle(r3d, synth, c5
     import torch.distributed as dist
     monkeypatch.setenv("R3D_FORCE_DIST", "1")
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
-    monkeypatch.setenv("MASTER_PORT", "29581")
+    import socket
+    with socket.socket() as sk:                                     # a free port (a fixed one may be taken on a shared host)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    monkeypatch.setenv("MASTER_PORT", str(port))
     monkeypatch.setenv("RANK", "0")
     monkeypatch.setenv("WORLD_SIZE", "1")
     monkeypatch.setenv("LOCAL_RANK", "0")
