@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(256) k_voxel_mean_t(const double *__restrict__
 // the same sums over the points IN SORTED ORDER (the sort wrote them, k_cs_emit): a voxel's members are one contiguous stretch, so
 // a lane streams whole cache lines instead of gathering 24 bytes from each; the next eight members are requested before the
 // current eight are added
-template <class T>
+template <class T, int R>
 __global__ void __launch_bounds__(256) k_voxel_mean_sorted(const double *__restrict__ sp, const int *__restrict__ starts, int64_t nseg, int64_t n,
                                                            double *__restrict__ out) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -530,23 +530,23 @@ __global__ void __launch_bounds__(256) k_voxel_mean_sorted(const double *__restr
     const int b = starts[s], e = s + 1 < nseg ? starts[s + 1] : (int)n, m = e - b;
     const double *__restrict__ p = sp + (int64_t)b * 3;
     T x = 0, y = 0, z = 0;
-    double cur[24], nxt[24];
+    double cur[3 * R], nxt[3 * R];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < R; u++) {
         const int64_t q = (int64_t)min(u, m - 1) * 3;
         cur[u * 3] = p[q]; cur[u * 3 + 1] = p[q + 1]; cur[u * 3 + 2] = p[q + 2];
     }
-    for (int i0 = 0; i0 < m; i0 += 8) {
+    for (int i0 = 0; i0 < m; i0 += R) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int64_t q = (int64_t)min(i0 + 8 + u, m - 1) * 3;
+        for (int u = 0; u < R; u++) {
+            const int64_t q = (int64_t)min(i0 + R + u, m - 1) * 3;
             nxt[u * 3] = p[q]; nxt[u * 3 + 1] = p[q + 1]; nxt[u * 3 + 2] = p[q + 2];
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++)
+        for (int u = 0; u < R; u++)
             if (i0 + u < m) { x += (T)cur[u * 3]; y += (T)cur[u * 3 + 1]; z += (T)cur[u * 3 + 2]; }
 #pragma unroll
-        for (int u = 0; u < 24; u++) cur[u] = nxt[u];
+        for (int u = 0; u < 3 * R; u++) cur[u] = nxt[u];
     }
     const T c = (T)m;
     out[s * 3] = (double)(x / c); out[s * 3 + 1] = (double)(y / c); out[s * 3 + 2] = (double)(z / c);
@@ -1773,8 +1773,9 @@ static inline int launch_voxel_mean(r3d_ctx *ctx, DevArena &ar, bool f32, const 
                                     double *out, const double *sorted = nullptr) {
     if (sorted) {   // `a` in sorted order is available (the sort wrote it): contiguous streams, no index list
         const unsigned nbs = (unsigned)((nseg + 255) / 256);
-        if (f32) k_voxel_mean_sorted<float><<<nbs, 256, 0, ctx->stream>>>(sorted, starts, nseg, n, out);
-        else k_voxel_mean_sorted<double><<<nbs, 256, 0, ctx->stream>>>(sorted, starts, nseg, n, out);
+        // R = 8 members per round trip: 4 / 8 / 16 measured 4.71 / 4.54-4.59 / 4.59-4.64 ms per C5 view, interleaved on one box
+        if (f32) k_voxel_mean_sorted<float, 8><<<nbs, 256, 0, ctx->stream>>>(sorted, starts, nseg, n, out);
+        else k_voxel_mean_sorted<double, 8><<<nbs, 256, 0, ctx->stream>>>(sorted, starts, nseg, n, out);
         R3D_HIP(ctx, hipGetLastError());
         return R3D_OK;
     }
