@@ -1003,6 +1003,7 @@ struct IcpState {
     // device clock (wall_clock64, 100 MHz) at the first and the latest step: the GPU-side duration of the loop, to tell a stall
     // of the device from a completion that reached the host late (R3D_ICP_DEBUG=1 prints both when they disagree)
     unsigned long long t_first, t_last;
+    int seq;                  // host mirror only: evaluations published so far (written LAST, after a system-scope fence)
 };
 __device__ __forceinline__ Rigid load_rigid(const IcpState *__restrict__ st) {
     Rigid T;
@@ -2191,8 +2192,22 @@ __host__ __device__ bool solve6_to_matrix(const double *s, double U[16]) {
 // t, t+64, ... in order, then a fixed shuffle tree => deterministic); thread 0 then does what the host loop of
 // RegistrationICP does between two evaluations: statistics, convergence test against the previous evaluation, update
 // (Umeyama or the 6x6 Gauss-Newton system) and T <- U T.
+// `mirror` (pinned host memory, device-visible): thread 0 publishes the state there after every step, fields first, then a
+// system-scope fence, then `seq`; the host polls `seq` / `done` in that memory instead of waiting for a copy and an event -- the
+// completion of a D2H copy + marker reached the host 16-57 ms late about once in 16 registrations of 1 M points (the device clock
+// in the state showed the device done on time: R3D_ICP_DEBUG), a kernel's own store does not go that way.
+__device__ __forceinline__ void icp_publish(const IcpState *st, IcpState *mirror) {
+    if (!mirror) return;
+    for (int i = 0; i < 16; i++) mirror->T[i] = st->T[i];
+    mirror->fit = st->fit; mirror->rmse = st->rmse; mirror->corr = st->corr;
+    mirror->evals = st->evals; mirror->converged = st->converged; mirror->iterations = st->iterations;
+    mirror->t_first = st->t_first; mirror->t_last = st->t_last;
+    mirror->done = st->done;
+    __threadfence_system();
+    *(volatile int *)&mirror->seq = st->evals;
+}
 __global__ void __launch_bounds__(1024) k_icp_step(const double *__restrict__ partial, int nblocks, IcpState *__restrict__ st, int64_t ns,
-                                                   int mode, int max_it, double rel_fit, double rel_rmse) {
+                                                   int mode, int max_it, double rel_fit, double rel_rmse, IcpState *__restrict__ mirror) {
     __shared__ double sums[32];
     if (st->done) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -2214,7 +2229,7 @@ __global__ void __launch_bounds__(1024) k_icp_step(const double *__restrict__ pa
     else if (k >= max_it) { st->iterations = max_it; stop = 1; }
     st->fit = fit; st->rmse = rmse; st->corr = sums[0];
     st->evals = k + 1;
-    if (stop) { st->done = 1; return; }
+    if (stop) { st->done = 1; icp_publish(st, mirror); return; }
     double U[16];
     for (int i = 0; i < 16; i++) U[i] = (i % 5 == 0);
     if (sums[0] > 0) {
@@ -2225,6 +2240,7 @@ __global__ void __launch_bounds__(1024) k_icp_step(const double *__restrict__ pa
     for (int i = 0; i < 16; i++) T[i] = st->T[i];
     mat4_mul(U, T, T);
     for (int i = 0; i < 16; i++) st->T[i] = T[i];
+    icp_publish(st, mirror);
 }
 
 int upload(r3d_ctx *ctx, DevArena &ar, const double *h, int64_t n3, double **d) {
@@ -2471,8 +2487,12 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
     if (ar.rc) return ar.rc;
     static_assert(sizeof(IcpState) <= ICP_SLOTS * sizeof(double), "the pinned landing buffer holds one IcpState");
     if (!ctx->icp_ev) R3D_HIP(ctx, hipEventCreateWithFlags(&ctx->icp_ev, hipEventDisableTiming));
-    if (!ctx->icp_host) R3D_HIP(ctx, hipHostMalloc((void **)&ctx->icp_host, ICP_SLOTS * sizeof(double), hipHostMallocDefault));
-    IcpState *hst = (IcpState *)ctx->icp_host;   // pinned: the per-batch D2H copy is a plain DMA, completion seen by polling the event
+    if (!ctx->icp_host) R3D_HIP(ctx, hipHostMalloc((void **)&ctx->icp_host, ICP_SLOTS * sizeof(double), hipHostMallocMapped));
+    IcpState *hst = (IcpState *)ctx->icp_host;   // pinned and mapped: k_icp_step publishes the state here, the host polls it
+    // R3D_ICP_WAIT=event: the round-1/2 form (D2H copy of the state + an event polled with hipEventQuery), kept for A/B
+    static const bool wait_event = [] { const char *e = getenv("R3D_ICP_WAIT"); return e && !strcmp(e, "event"); }();
+    IcpState *d_mirror = nullptr;
+    if (!wait_event) R3D_HIP(ctx, hipHostGetDevicePointer((void **)&d_mirror, hst, 0));
     memset(hst, 0, sizeof *hst);
     memcpy(hst->T, T, sizeof T);
     R3D_HIP(ctx, hipMemcpyAsync(d_st, hst, sizeof *hst, hipMemcpyHostToDevice, ctx->stream));
@@ -2501,7 +2521,7 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
 #undef R3D_ICP_MODES
 #undef R3D_ICP_LAUNCH
         }
-        k_icp_step<<<1, 1024, 0, ctx->stream>>>(d_part, nblocks, d_st, ns, p->mode, max_it, p->relative_fitness, p->relative_rmse);
+        k_icp_step<<<1, 1024, 0, ctx->stream>>>(d_part, nblocks, d_st, ns, p->mode, max_it, p->relative_fitness, p->relative_rmse, d_mirror);
     };
     R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const auto t_loop = std::chrono::steady_clock::now();
@@ -2513,19 +2533,28 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
     for (int enq = 0; enq < max_it + 1;) {
         for (int b = 0; b < ICP_BATCH && enq < max_it + 1; b++, enq++) enqueue_eval();
         R3D_HIP(ctx, hipGetLastError());
-        R3D_HIP(ctx, hipMemcpyAsync(hst, d_st, sizeof *hst, hipMemcpyDeviceToHost, ctx->stream));
-        R3D_HIP(ctx, hipEventRecord(ctx->icp_ev, ctx->stream));
-        // Bounded wait.  A tight spin for the first 200 us (a batch of a small cloud is shorter than a sleep), then the thread
-        // yields between polls: a bare hipEventQuery spin hammers the runtime's stream lock, which the completion handlers of a
-        // profiler's dispatch interception also need (a rocprofv3 --pmc pass of the 1 M-point loop made no progress for 7
-        // minutes with the bare spin).  The deadline scales with the work enqueued (serialised counter passes are ~100x
-        // slower than a plain run); on expiry the call fails with the last state read so the caller exits non-zero.
+        if (wait_event) {
+            R3D_HIP(ctx, hipMemcpyAsync(hst, d_st, sizeof *hst, hipMemcpyDeviceToHost, ctx->stream));
+            R3D_HIP(ctx, hipEventRecord(ctx->icp_ev, ctx->stream));
+        }
+        // Bounded wait for the batch: either the state k_icp_step publishes in the mapped host buffer (`seq` reaches the number
+        // of evaluations enqueued, or `done`), or (R3D_ICP_WAIT=event) the event behind a D2H copy of the state.  A tight spin for
+        // the first 200 us (a batch of a small cloud is shorter than a sleep), then the thread yields between polls (a bare
+        // hipEventQuery spin hammers the runtime's stream lock, which a profiler's completion handlers also need).  The deadline
+        // scales with the work enqueued (serialised counter passes are ~100x slower than a plain run); on expiry the call fails
+        // with the last state read so the caller exits non-zero.
         const auto t_poll = std::chrono::steady_clock::now();
         const double deadline_s = 20.0 + 2e-6 * (double)(ns + nt) * ICP_BATCH;
         for (unsigned spins = 0;; spins++) {
-            const hipError_t q = hipEventQuery(ctx->icp_ev);
-            if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) return r3d_fail(ctx, R3D_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+            if (wait_event) {
+                const hipError_t q = hipEventQuery(ctx->icp_ev);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) return r3d_fail(ctx, R3D_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+            } else {
+                const int seq = *(volatile int *)&hst->seq;
+                std::atomic_thread_fence(std::memory_order_acquire);
+                if (seq >= enq || (seq > 0 && *(volatile int *)&hst->done)) break;
+            }
             if ((spins & 63) != 63) continue;
             const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_poll).count();
             if (waited > deadline_s) {
@@ -2538,6 +2567,8 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
         if (hst->done) break;
     }
     if (!hst->done) return r3d_fail(ctx, R3D_E_HIP, "registration loop did not finish (%d evaluations)", hst->evals);
+    // (in mirror mode evaluations enqueued behind the step that ended the loop may still be in flight: they return at their first
+    // instruction (`done`), and everything this call or the next enqueues is ordered behind them on the same stream)
     memcpy(T, hst->T, sizeof T);
     const int it = hst->iterations, converged = hst->converged;
     const double fit = hst->fit, rmse = hst->rmse, ncorr = hst->corr;
@@ -2557,7 +2588,7 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
         if (dbg) {
             const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count();
             const double dev_ms = (double)(hst->t_last - hst->t_first) * 1e-5;   // 100 MHz ticks, first step to last step
-            if (host_ms > 5.0 + 3.0 * dev_ms)
+            if (host_ms > 10.0 || host_ms > 5.0 + 3.0 * dev_ms)
                 fprintf(stderr, "[r3d icp] loop: host %.3f ms, device first-to-last step %.3f ms (%d evaluations): the device %s\n", host_ms, dev_ms,
                         hst->evals, dev_ms > 0.5 * host_ms ? "itself was stalled" : "finished on time, the completion reached the host late");
         }
