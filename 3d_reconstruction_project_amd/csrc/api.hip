@@ -143,7 +143,6 @@ void r3d_destroy(r3d_ctx *ctx) {
     if (ctx->icp_ev) (void)hipEventDestroy(ctx->icp_ev);
     if (ctx->icp_host) (void)hipHostFree(ctx->icp_host);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
-    if (ctx->pin_ev) (void)hipEventDestroy(ctx->pin_ev);
     for (r3d_buf &b : ctx->cloud_bufs)
         if (b.p) (void)hipFree(b.p);
     for (r3d_buf &b : ctx->pp_bufs)

@@ -89,6 +89,25 @@ __global__ void __launch_bounds__(256) k_bbox_partial(const double *__restrict__
     if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = sm[threadIdx.x][0];
 }
 
+// second stage: one workgroup folds the per-workgroup boxes into one (6 doubles), so the host reads 48 bytes
+__global__ void __launch_bounds__(256) k_bbox_final(const double *__restrict__ part, int nb, double *__restrict__ out6) {
+    __shared__ double sm[6][256];
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int b = threadIdx.x; b < nb; b += 256)
+        for (int a = 0; a < 3; a++) { mn[a] = fmin(mn[a], part[b * 6 + a]); mx[a] = fmax(mx[a], part[b * 6 + 3 + a]); }
+    for (int a = 0; a < 3; a++) { sm[a][threadIdx.x] = mn[a]; sm[3 + a][threadIdx.x] = mx[a]; }
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int a = 0; a < 3; a++) {
+                sm[a][threadIdx.x] = fmin(sm[a][threadIdx.x], sm[a][threadIdx.x + s]);
+                sm[3 + a][threadIdx.x] = fmax(sm[3 + a][threadIdx.x], sm[3 + a][threadIdx.x + s]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) out6[threadIdx.x] = sm[threadIdx.x][0];
+}
+
 // ------------------------------------------------------------------------------------------------ keys
 // KEY = unsigned (the key space fits 32 bits: half the bytes through every radix pass) or unsigned long long
 template <class KEY>
@@ -1728,43 +1747,61 @@ struct DevArena {  // simple bump allocator over ctx->cloud_bufs (grow-only, reu
     }
 };
 
-// Small device -> host reads between kernels (counts, bounding boxes): every piece lands in the context's PINNED buffer with an
-// asynchronous copy and ONE stream synchronise follows.  (A hipMemcpyAsync into pageable memory is staged and waited for piece by
-// piece: two 4-byte reads cost two host round trips of ~20 us each on this box, the kernel trace shows them as separate gaps.)
+// Small device -> host reads between kernels (counts, bounding boxes).  k_publish copies every piece into the context's pinned,
+// device-mapped buffer and then stores a sequence number there (system-scope fence in between); the host polls that number in
+// memory.  No copy command, no marker, no runtime call in the wait: two staged 4-byte hipMemcpyAsync + a blocking synchronise
+// cost ~50 us of idle GPU per round trip, two pinned copies + an event poll ~25 us (and were, in the registration loop, the part
+// whose completion sometimes reached the host tens of milliseconds late), this form ~15 us.
+struct PubDesc { const void *src[8]; unsigned off[8], bytes[8]; int n; unsigned seq; };
+__global__ void __launch_bounds__(256) k_publish(PubDesc d, char *__restrict__ host) {
+    for (int q = 0; q < d.n; q++) {
+        const char *s = (const char *)d.src[q];
+        for (unsigned i = threadIdx.x * 4; i < d.bytes[q]; i += 256 * 4) *(int *)(host + d.off[q] + i) = *(const int *)(s + i);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) *(volatile unsigned *)host = d.seq;
+}
 struct PinRead {
     r3d_ctx *ctx;
-    size_t off = 0;
-    struct Piece { void *host; size_t off, bytes; } piece[8];
-    int n = 0;
-    explicit PinRead(r3d_ctx *c) : ctx(c) {}
-    int add(void *host, const void *dev, size_t bytes) {
+    size_t off = 64;   // the first 64 bytes of the buffer hold the sequence number
+    PubDesc d;
+    void *host[8];
+    explicit PinRead(r3d_ctx *c) : ctx(c) { d.n = 0; }
+    int add(void *host_dst, const void *dev, size_t bytes) {   // bytes: a multiple of 4
         if (!ctx->pin) {
-            hipError_t e = hipHostMalloc(&ctx->pin, R3D_PIN_BYTES);
+            hipError_t e = hipHostMalloc(&ctx->pin, R3D_PIN_BYTES, hipHostMallocMapped);
             if (e != hipSuccess) { ctx->pin = nullptr; return r3d_fail(ctx, R3D_E_OOM, "hipHostMalloc(%d) failed: %s", R3D_PIN_BYTES, hipGetErrorString(e)); }
+            memset(ctx->pin, 0, 64);
         }
-        if (n >= 8 || off + bytes > R3D_PIN_BYTES) return r3d_fail(ctx, R3D_E_HIP, "PinRead: too much for one read-back");
-        R3D_HIP(ctx, hipMemcpyAsync((char *)ctx->pin + off, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        piece[n++] = Piece{host, off, bytes};
+        if (d.n >= 8 || (bytes & 3) || off + bytes > R3D_PIN_BYTES) return r3d_fail(ctx, R3D_E_HIP, "PinRead: too much for one read-back");
+        d.src[d.n] = dev; d.off[d.n] = (unsigned)off; d.bytes[d.n] = (unsigned)bytes;
+        host[d.n++] = host_dst;
         off += (bytes + 15) & ~(size_t)15;
         return R3D_OK;
     }
     int wait() {
-        // a blocking stream synchronise may put the thread to sleep for a scheduler tick (the kernel trace showed ~40 us between the
-        // copy and the next launch); the reads are a few microseconds away, so poll an event briefly first, then wait properly
-        if (!ctx->pin_ev) R3D_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_ev, hipEventDisableTiming));
-        R3D_HIP(ctx, hipEventRecord(ctx->pin_ev, ctx->stream));
-        bool done = false;
+        char *dpin = nullptr;
+        R3D_HIP(ctx, hipHostGetDevicePointer((void **)&dpin, ctx->pin, 0));
+        d.seq = ++ctx->pin_seq;
+        k_publish<<<1, 256, 0, ctx->stream>>>(d, dpin);
+        R3D_HIP(ctx, hipGetLastError());
+        // the read is a few microseconds away: poll the sequence number briefly, then wait properly (a blocking synchronise may put
+        // the thread to sleep for a scheduler tick)
         const auto t0 = std::chrono::steady_clock::now();
+        bool done = false;
         for (unsigned spins = 0; !done; spins++) {
-            const hipError_t q = hipEventQuery(ctx->pin_ev);
-            if (q == hipSuccess) { done = true; break; }
-            if (q != hipErrorNotReady) return r3d_fail(ctx, R3D_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
-            if ((spins & 15) == 15 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 3e-4) break;
+            if (*(volatile unsigned *)ctx->pin == d.seq) { done = true; break; }
+            if ((spins & 255) == 255 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 1e-3) break;
         }
-        if (!done) R3D_HIP(ctx, hipEventSynchronize(ctx->pin_ev));
-        for (int i = 0; i < n; i++) memcpy(piece[i].host, (const char *)ctx->pin + piece[i].off, piece[i].bytes);
-        n = 0;
-        off = 0;
+        if (!done) {
+            R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (*(volatile unsigned *)ctx->pin != d.seq) return r3d_fail(ctx, R3D_E_HIP, "PinRead: the published sequence number did not arrive");
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        for (int i = 0; i < d.n; i++) memcpy(host[i], (const char *)ctx->pin + d.off[i], d.bytes[i]);
+        d.n = 0;
+        off = 64;
         return R3D_OK;
     }
 };
@@ -1807,19 +1844,18 @@ struct Grid {
 
 int cloud_bbox(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, double mn[3], double mx[3]) {
     const int nb = (int)std::min<int64_t>((n + 255) / 256, 1024);
-    double *part = (double *)ar.get((size_t)nb * 6 * 8);
+    double *part = (double *)ar.get((size_t)(nb + 1) * 6 * 8);
     if (ar.rc) return ar.rc;
     k_bbox_partial<<<nb, 256, 0, ctx->stream>>>(d_pts, n, part);
+    k_bbox_final<<<1, 256, 0, ctx->stream>>>(part, nb, part + (size_t)nb * 6);
     R3D_HIP(ctx, hipGetLastError());
-    std::vector<double> h((size_t)nb * 6);
+    double h[6];
     {
         PinRead rd(ctx);
         int prc;
-        if ((prc = rd.add(h.data(), part, h.size() * 8)) || (prc = rd.wait())) return prc;
+        if ((prc = rd.add(h, part + (size_t)nb * 6, sizeof h)) || (prc = rd.wait())) return prc;
     }
-    for (int a = 0; a < 3; a++) { mn[a] = 1e300; mx[a] = -1e300; }
-    for (int b = 0; b < nb; b++)
-        for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], h[(size_t)b * 6 + a]); mx[a] = std::max(mx[a], h[(size_t)b * 6 + 3 + a]); }
+    for (int a = 0; a < 3; a++) { mn[a] = h[a]; mx[a] = h[3 + a]; }
     // a point at infinity (e.g. a zero disparity reprojected through Q) or a NaN has no cell: refuse instead of building a
     // grid around it (fmin/fmax drop NaNs, so those show up as an untouched +-1e300 bound only if every value is NaN)
     for (int a = 0; a < 3; a++)

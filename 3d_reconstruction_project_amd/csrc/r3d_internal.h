@@ -70,7 +70,7 @@ struct r3d_ctx {
     std::vector<r3d_buf> cloud_bufs;
     hipEvent_t icp_ev = nullptr;   // polled once per registration iteration
     double *icp_host = nullptr;    // pinned landing buffer of the per-iteration sums
-    hipEvent_t pin_ev = nullptr;   // completion of a PinRead (polled briefly, then waited for)
+    unsigned pin_seq = 0;          // sequence number of the latest PinRead
     void *pin = nullptr;           // pinned landing buffer of the small device -> host reads between kernels (R3D_PIN_BYTES)
     // pre/post-processing workspace (prepost.hip)
     std::vector<r3d_buf> pp_bufs;
