@@ -1758,9 +1758,14 @@ __global__ void __launch_bounds__(256) k_publish(PubDesc d, char *__restrict__ h
         const char *s = (const char *)d.src[q];
         for (unsigned i = threadIdx.x * 4; i < d.bytes[q]; i += 256 * 4) *(int *)(host + d.off[q] + i) = *(const int *)(s + i);
     }
+    // every writer makes its stores visible at system scope, the barrier orders them before thread 0, which releases once more before
+    // the sequence number goes out (PCIe keeps posted writes of one device in order)
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) *(volatile unsigned *)host = d.seq;
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        *(volatile unsigned *)host = d.seq;
+    }
 }
 struct PinRead {
     r3d_ctx *ctx;
