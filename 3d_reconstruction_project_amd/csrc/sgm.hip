@@ -1404,6 +1404,243 @@ __global__ void __launch_bounds__(64) k_vscan2(const int *__restrict__ cvol, con
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Winner-take-all + uniqueness + sub-pixel of one disparity vector held in registers in the generic mapping (the arithmetic
+// of k_vscan2's row step as a function; group-uniform results; no LDS, no barrier).
+template <int NPL, int LPC>
+__device__ __forceinline__ void wta_regs(const int (&S)[NPL], int k, bool valid, const SgmGeom &g, int a, float inv_a, int &dsp_out,
+                                         int &minS_out) {
+    int key = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+        const int d0 = 2 * NPL * k + 2 * j;
+        const int k0 = (int)((unsigned)S[j] << 16) | d0;
+        const int k1 = (S[j] & (int)0xffff0000) | (d0 + 1);
+        key = min(key, min(k0, k1));
+    }
+    if (!valid) key = 0x7fffffff;
+    key = grp_allmin<LPC>(key);
+    const int best = key & 0xffff, minS = key >> 16;
+    auto fetch_s = [&](int d) -> int {
+        const int j = (d >> 1) % NPL;
+        int v;
+        if constexpr (NPL == 16) {
+            const bool b0 = j & 1, b1 = j & 2, b2 = j & 4;
+            const int t0 = b0 ? S[1] : S[0], t1 = b0 ? S[3] : S[2], t2 = b0 ? S[5] : S[4], t3 = b0 ? S[7] : S[6];
+            const int t4 = b0 ? S[9] : S[8], t5 = b0 ? S[11] : S[10], t6 = b0 ? S[13] : S[12], t7 = b0 ? S[15] : S[14];
+            const int u0 = b1 ? t1 : t0, u1 = b1 ? t3 : t2, u2 = b1 ? t5 : t4, u3 = b1 ? t7 : t6;
+            const int w0 = b2 ? u1 : u0, w1 = b2 ? u3 : u2;
+            v = (j & 8) ? w1 : w0;
+        } else if constexpr (NPL == 8) {
+            const int t0 = (j & 1) ? S[1] : S[0], t1 = (j & 1) ? S[3] : S[2], t2 = (j & 1) ? S[5] : S[4], t3 = (j & 1) ? S[7] : S[6];
+            const int u0 = (j & 2) ? t1 : t0, u1 = (j & 2) ? t3 : t2;
+            v = (j & 4) ? u1 : u0;
+        } else {
+            const int t0 = (j & 1) ? S[1] : S[0], t1 = (j & 1) ? S[3] : S[2];
+            v = (j & 2) ? t1 : t0;
+        }
+        const int val = (d & 1) ? hi16(v) : lo16(v);
+        return grp_allmin<LPC>(((d / (2 * NPL)) == k) ? val : 0x7fffffff);
+    };
+    const int dm = max(best - 1, 0), dp = min(best + 1, g.D - 1);
+    const int sm = fetch_s(dm), sp = fetch_s(dp);
+    bool bad = false;
+    if (g.uniq > 0) {
+        const int T = ceil_div_small(minS * 100, a, inv_a);
+        int cnt;
+        if (T > 32767) cnt = valid ? 2 * NPL : 0;
+        else {
+            const int Tpk = pk_dup(max(T, -32768));
+            int acc = 0;
+#pragma unroll
+            for (int j = 0; j < NPL; j++) {
+                const int diff = as_i(__builtin_elementwise_sub_sat(as_s(S[j]), as_s(Tpk)));
+                acc = pk_sub(acc, as_i(as_s(diff) >> (s16x2){15, 15}));
+            }
+            cnt = valid ? lo16(acc) + hi16(acc) : 0;
+        }
+        cnt = grp_allsum<LPC>(cnt);
+        int win = (minS < T) ? 1 : 0;
+        if (best > 0 && sm < T) win++;
+        if (best < g.D - 1 && sp < T) win++;
+        bad = cnt > win;
+    }
+    int dsp = g.invalid;
+    if (!bad) {
+        dsp = best * 16;
+        if (0 < best && best < g.D - 1) {
+            const int den = max(sm + sp - 2 * minS, 1);
+            dsp += trunc_div_small((sm - sp) * 16 + den, den * 2);
+        }
+        dsp += g.minD * 16;
+    }
+    dsp_out = dsp;
+    minS_out = minS;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_vscan3 (R3D_SGM_IMPL=v4): the vertical pass RECOMPUTES the block cost instead of reading it.  Same result as
+// k_vscan2; HBM traffic: the two record images + the L_left + L_right volume (read once) -- the 2 GB read of C is gone,
+// and so are the special stripe-top rows (cspec): the stripe's own march produces them.
+// Structure = k_cost2's producer loop (one workgroup per STRIPE x column tile marching down the stripe from its first
+// warm-up row; pixel cost -> vertical window in registers -> LDS tile -> horizontal box sum), whose freshly summed C
+// vector -- still in registers, in the 16-disparities-per-lane mapping -- feeds the L_top recurrence, S = (L_l + L_r) + L_t,
+// winner-take-all, uniqueness and sub-pixel of the same lane group.  The L_l + L_r rows are requested two rows ahead
+// into two register buffers (the loop is unrolled by two, so buffer and LDS slot are static).
+template <int LPC, int SH2, int NWAVE>
+__global__ void __launch_bounds__(NWAVE * 64) k_vscan3(const uint2 *__restrict__ recL, const uint2 *__restrict__ recR, SgmGeom g,
+                                                       const int *__restrict__ hvol, float inv_a, int16_t *__restrict__ raw,
+                                                       int16_t *__restrict__ mins) {
+    constexpr int NPL = 8, CW = 64 / LPC, TC = NWAVE * CW, TO = TC - 2 * SH2, DP = 16 * LPC, DPW = NPL * LPC;
+    constexpr int R = 2 * SH2 + 1, NRR = TC + DP, NT = NWAVE * 64;
+    constexpr int SWN = NRR * 6 + (NRR / 16 + 1) * 8;   // pair-word layout: see k_cost2
+    __shared__ int sW[2][SWN];
+    __shared__ uint2 sL[2][TC];
+    __shared__ int sV[2][TC * DPW];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, k = lane % LPC, grp = lane / LPC;
+    const int cl = w * CW + grp;
+    const int t0 = blockIdx.x * TO;
+    const int xc = min(max(t0 - SH2 + cl, 0), g.W1 - 1);
+    const int x = xc + g.minX1;
+    const int r_base = max(t0 - SH2, 0) + g.minX1 - g.minD - (DP - 1);
+    const int ri0 = min(max(x - g.minD - 16 * k - r_base, 15), NRR - 1);
+    const size_t rowWords = (size_t)g.W1 * DPW;
+    const int n = blockIdx.y;
+    const int y0 = max(min(n * g.stripe_sz - g.overlap, g.H), 0), y1 = min((n + 1) * g.stripe_sz, g.H);
+    const int out_start = min(n * g.stripe_sz, g.H);
+    if (y0 >= y1) return;
+    auto crow = [&](int yy) { return min(max(yy, y0), g.H - 1); };
+    const bool lane_valid = 16 * k < g.D, first = k == 0, last = k == LPC - 1;
+    const int P1pk = pk_dup(g.P1), a = 100 - g.uniq;
+    int LT[NPL], ltmin = 0;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) LT[j] = lane_valid ? 0 : PADPK;
+
+    static_assert(NRR <= NT, "one pair-word record per thread");
+    uint2 pfL = make_uint2(0, 0), pfA = make_uint2(0, 0), pfB = make_uint2(0, 0);
+    auto fetch = [&](int row) {
+        const uint2 *lr = recL + (size_t)row * g.W, *rr = recR + (size_t)row * g.W;
+        if (tid < TC) pfL = lr[min(max(t0 - SH2 + tid, 0), g.W1 - 1) + g.minX1];
+        if (tid < NRR) {
+            const int r = r_base + tid;
+            pfA = rr[min(max(r, 0), g.W - 1)];
+            pfB = rr[min(max(r - 1, 0), g.W - 1)];
+        }
+    };
+    auto commit = [&](int b) {
+        if (tid < TC) sL[b][tid] = pfL;
+        if (tid < NRR) {
+            const uint2 A = pfA, B = pfB;
+            int *o = &sW[b][tid * 6 + (tid >> 4) * 8];
+            o[0] = __builtin_amdgcn_perm(B.x, A.x, 0x0c040c00); o[1] = __builtin_amdgcn_perm(B.x, A.x, 0x0c050c01);
+            o[2] = __builtin_amdgcn_perm(B.x, A.x, 0x0c060c02); o[3] = __builtin_amdgcn_perm(B.x, A.x, 0x0c070c03);
+            o[4] = __builtin_amdgcn_perm(B.y, A.y, 0x0c040c00); o[5] = __builtin_amdgcn_perm(B.y, A.y, 0x0c050c01);
+        }
+    };
+    auto pixel_cost = [&](int b, int (&pix)[NPL]) {
+        const uint2 lr = sL[b][cl];
+        const int Ug = __builtin_amdgcn_perm(lr.x, lr.x, 0x0c000c00), Ug0 = __builtin_amdgcn_perm(lr.x, lr.x, 0x0c010c01);
+        const int Ug1 = __builtin_amdgcn_perm(lr.x, lr.x, 0x0c020c02), Ui = __builtin_amdgcn_perm(lr.x, lr.x, 0x0c030c03);
+        const int Ui0 = __builtin_amdgcn_perm(lr.y, lr.y, 0x0c000c00), Ui1 = __builtin_amdgcn_perm(lr.y, lr.y, 0x0c010c01);
+#pragma unroll
+        for (int j = 0; j < NPL; j++) {
+            const int rj = ri0 - 2 * j;
+            const int2 *p = (const int2 *)&sW[b][rj * 6 + (rj >> 4) * 8];
+            const int2 aa = p[0], bq = p[1], c = p[2];
+            const int cg = bt_cost_pk(Ug, Ug0, Ug1, aa.x, aa.y, bq.x);
+            const int ci = bt_cost_pk(Ui, Ui0, Ui1, bq.y, c.x, c.y);
+            pix[j] = pk_add(cg, (ci >> 2) & 0x3fff3fff);
+        }
+    };
+    int ring[R][NPL / 2], vs[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; j++) vs[j] = 0;
+#pragma unroll
+    for (int q = 0; q < R; q++)
+#pragma unroll
+        for (int j = 0; j < NPL / 2; j++) ring[q][j] = 0;
+    const int ocol = t0 - SH2 + cl;                        // cost column of this lane group
+    const bool is_out = cl >= SH2 && cl < TC - SH2 && ocol < g.W1;
+    const int tile_x0 = t0 - SH2;
+    const int *hptr = hvol + (size_t)min(max(ocol, 0), g.W1 - 1) * DPW + k * NPL;
+    // L_left + L_right of output row y (only rows the stripe owns are ever read)
+    auto hload = [&](int y, int (&hb)[NPL]) {
+        if (y >= out_start && y < y1) {
+            const int4 h0 = *(const int4 *)(hptr + (size_t)y * rowWords), h1 = *(const int4 *)(hptr + (size_t)y * rowWords + 4);
+            hb[0] = h0.x; hb[1] = h0.y; hb[2] = h0.z; hb[3] = h0.w; hb[4] = h1.x; hb[5] = h1.y; hb[6] = h1.z; hb[7] = h1.w;
+        }
+    };
+    int hA[NPL], hB[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; j++) hA[j] = hB[j] = 0;
+    // iteration t: image row e = y0 - SH2 + t enters the vertical window (inputs in LDS buffer b = t & 1, staged one
+    // iteration earlier); from t = 2*SH2 on the window is full and output row y = y0 + t - 2*SH2 is produced
+    auto iter = [&](int t, int b, int (&hb)[NPL]) {
+        int pn[NPL];
+        pixel_cost(b, pn);
+#pragma unroll
+        for (int j = 0; j < NPL / 2; j++) {
+            const int old = ring[0][j];
+            vs[2 * j] = pk_add(pk_sub(vs[2 * j], __builtin_amdgcn_perm(old, old, 0x0c010c00)), pn[2 * j]);
+            vs[2 * j + 1] = pk_add(pk_sub(vs[2 * j + 1], __builtin_amdgcn_perm(old, old, 0x0c030c02)), pn[2 * j + 1]);
+        }
+#pragma unroll
+        for (int q = 0; q + 1 < R; q++)
+#pragma unroll
+            for (int j = 0; j < NPL / 2; j++) ring[q][j] = ring[q + 1][j];
+#pragma unroll
+        for (int j = 0; j < NPL / 2; j++) ring[R - 1][j] = __builtin_amdgcn_perm(pn[2 * j + 1], pn[2 * j], 0x06040200);
+        const bool outp = t >= 2 * SH2;
+        if (outp) {
+            *(int4 *)&sV[b][cl * DPW + (DPW / 2) * (cl & 1) + 4 * k] = make_int4(vs[0], vs[1], vs[2], vs[3]);
+            *(int4 *)&sV[b][cl * DPW + (DPW / 2) * ((cl & 1) ^ 1) + 4 * k] = make_int4(vs[4], vs[5], vs[6], vs[7]);
+        }
+        commit(b ^ 1);
+        fetch(crow(y0 - SH2 + t + 2));
+        __syncthreads();
+        if (outp && is_out) {
+            int c[NPL];
+#pragma unroll
+            for (int j = 0; j < NPL; j++) c[j] = 0;
+#pragma unroll
+            for (int i = -SH2; i <= SH2; i++) {
+                const int col = min(max(tile_x0 + cl + i, 0), g.W1 - 1) - tile_x0;
+                const int4 v0 = *(const int4 *)&sV[b][col * DPW + (DPW / 2) * (col & 1) + 4 * k];
+                const int4 v1 = *(const int4 *)&sV[b][col * DPW + (DPW / 2) * ((col & 1) ^ 1) + 4 * k];
+                c[0] = pk_add(c[0], v0.x); c[1] = pk_add(c[1], v0.y); c[2] = pk_add(c[2], v0.z); c[3] = pk_add(c[3], v0.w);
+                c[4] = pk_add(c[4], v1.x); c[5] = pk_add(c[5], v1.y); c[6] = pk_add(c[6], v1.z); c[7] = pk_add(c[7], v1.w);
+            }
+            sgm_step_g<NPL, LPC, true>(LT, ltmin, c, P1pk, g.P2, first, last, lane_valid);
+            const int y = y0 + t - 2 * SH2;
+            if (y >= out_start) {
+                int S[NPL];
+#pragma unroll
+                for (int j = 0; j < NPL; j++) S[j] = pk_add_sat(hb[j], LT[j]);
+                hload(y + 2, hb);
+                int dsp, mS;
+                wta_regs<NPL, LPC>(S, k, lane_valid, g, a, inv_a, dsp, mS);
+                if (first) {
+                    const size_t o = (size_t)y * g.W + g.minX1 + ocol;
+                    raw[o] = (int16_t)dsp;
+                    mins[o] = (int16_t)mS;
+                }
+            } else
+                hload(y + 2, hb);
+        }
+    };
+    fetch(crow(y0 - SH2));
+    commit(0);
+    fetch(crow(y0 - SH2 + 1));
+    if (is_out) { hload(y0, hA); hload(y0 + 1, hB); }
+    __syncthreads();
+    const int niter = (y1 - y0) + 2 * SH2;
+#pragma unroll 1
+    for (int t = 0; t < niter; t += 2) {
+        iter(t, 0, hA);
+        if (t + 1 < niter) iter(t + 1, 1, hB);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // k_lrcheck: per row: rebuild OpenCV's disp2 / disp2cost scatter (lowest cost wins, among equal costs the
 // LARGEST x, because the original sweeps x right-to-left with a strict '>') with one LDS atomicMin on the key
 // (cost+32768)<<16 | (w-1-x), then apply the two-sided disp12MaxDiff test.  Output covers all w columns.
@@ -1851,6 +2088,35 @@ int launch_vscan2(r3d_ctx *ctx, r3d_sgm_ws &ws, hipStream_t st, const SgmGeom &g
     return (int)hipGetLastError();
 }
 
+// launcher of k_vscan3 (the vertical pass that recomputes C): LPC = DP / 16 lanes per column as in k_cost2, one workgroup per
+// stripe and 64 / 32-column tile (2 * SH2 halo columns)
+template <int LPC>
+int launch_vscan3_l(hipStream_t st, const r3d_sgm_ws &ws, const SgmGeom &g, float inv_a, const int *hsum, int16_t *raw, int16_t *mins) {
+    constexpr int NWAVE = 8, CW = 64 / LPC, TC = NWAVE * CW;
+    const uint2 *rl = (const uint2 *)ws.rec_l.p, *rr = (const uint2 *)ws.rec_r.p;
+#define R3D_VS3(S)                                                                                                          \
+    case S: {                                                                                                               \
+        constexpr int TO = TC - 2 * S;                                                                                      \
+        if constexpr (TO > 0)                                                                                               \
+            k_vscan3<LPC, S, NWAVE><<<dim3((g.W1 + TO - 1) / TO, 4), NWAVE * 64, 0, st>>>(rl, rr, g, hsum, inv_a, raw, mins); \
+        else return -1;                                                                                                     \
+    } break;
+    switch (g.SH2) {
+        R3D_VS3(0) R3D_VS3(1) R3D_VS3(2) R3D_VS3(3) R3D_VS3(4) R3D_VS3(5)
+        default: return -1;
+    }
+#undef R3D_VS3
+    return (int)hipGetLastError();
+}
+int launch_vscan3(hipStream_t st, const r3d_sgm_ws &ws, const SgmGeom &g, float inv_a, const int *hsum, int16_t *raw, int16_t *mins) {
+    switch (g.DP) {
+        case 32: return launch_vscan3_l<2>(st, ws, g, inv_a, hsum, raw, mins);
+        case 64: return launch_vscan3_l<4>(st, ws, g, inv_a, hsum, raw, mins);
+        case 128: return launch_vscan3_l<8>(st, ws, g, inv_a, hsum, raw, mins);
+        default: return launch_vscan3_l<16>(st, ws, g, inv_a, hsum, raw, mins);
+    }
+}
+
 }  // namespace
 
 int r3d_streambench_run(r3d_ctx *ctx, int mode, int rows, size_t row_bytes, int write, int delay, int reps, float *ms) {
@@ -1958,7 +2224,7 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
     // implementation generations kept side by side for A/B measurements: R3D_SGM_IMPL = v1 | v2 (default) | v3.
     // v3 (L_top fused into the cost kernel, WTA fused into hscan) moves 2.7 GB less but measured 5.0 ms against 3.45 ms
     // for v2 on C2, so it is not the default.
-    static const int impl = [] { const char *e = getenv("R3D_SGM_IMPL"); return !e ? 2 : !strcmp(e, "v1") ? 1 : !strcmp(e, "v3") ? 3 : 2; }();
+    static const int impl = [] { const char *e = getenv("R3D_SGM_IMPL"); return !e ? 2 : !strcmp(e, "v1") ? 1 : !strcmp(e, "v3") ? 3 : !strcmp(e, "v4") ? 4 : 2; }();
     const bool use_v1 = impl == 1;
     ctx->last_impl = impl;
     const float inv_a = 1.0f / (float)(100 - g.uniq);
@@ -2128,7 +2394,12 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
     {
         constexpr int CPW = 8;
         dim3 grid((g.W1 + CPW - 1) / CPW, 4);
-        if (!use_v1) {
+        if (impl == 4) {
+            // v4: the vertical pass recomputes C from the record images (k_vscan3); cost / cspec are not read again
+            if (int e = launch_vscan3(st, ws, g, inv_a, (const int *)ws.hsum.p, (int16_t *)ws.raw.p, (int16_t *)ws.mins.p))
+                return e < 0 ? r3d_fail(ctx, R3D_E_UNSUPPORTED, "k_vscan3: no instantiation for this block size")
+                             : r3d_fail(ctx, R3D_E_HIP, "k_vscan3 launch failed: %s", hipGetErrorString((hipError_t)e));
+        } else if (!use_v1) {
             // mapping per disparity-slot layout: see launch_vscan2
             if (int e = launch_vscan2(ctx, ws, st, g, inv_a, (const int *)ws.cost.p, (const int *)ws.cspec.p, (const int *)ws.hsum.p,
                                       (int16_t *)ws.raw.p, (int16_t *)ws.mins.p))

@@ -188,9 +188,10 @@ def test_randomised_parameter_sweep(r3d):
         assert np.array_equal(got, want), f"case {case}: W={W} H={H} D={D} {kw}: {(got != want).sum()} pixels differ"
 
 
-@pytest.mark.parametrize("impl", ["v1", "v3"])
+@pytest.mark.parametrize("impl", ["v1", "v2", "v3", "v4"])
 def test_alternative_kernel_generations_stay_bit_exact(impl):
-    """R3D_SGM_IMPL selects the kernel generation at library load; v1 and v3 are kept for A/B measurements."""
+    """R3D_SGM_IMPL selects the kernel generation at library load: v2 reads the cost volume in its vertical pass, v4
+    recomputes it there (k_vscan3); v1 and v3 are kept for A/B measurements."""
     import subprocess
     import sys
     from tests.conftest import ROOT
@@ -200,7 +201,7 @@ def test_alternative_kernel_generations_stay_bit_exact(impl):
         "r3d = importlib.import_module('3d_reconstruction_project_amd')\n"
         "from oracle import sgbm_oracle as so\n"
         "kw = dict(minDisparity=0, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1, uniquenessRatio=15, speckleWindowSize=0, speckleRange=2, preFilterCap=63)\n"
-        "for W, H, D, seed in ((333, 121, 64, 2), (500, 203, 128, 5), (400, 90, 256, 6), (301, 77, 48, 7)):\n"
+        "for W, H, D, seed in ((333, 121, 64, 2), (500, 203, 128, 5), (400, 90, 256, 6), (301, 77, 48, 7), (190, 64, 16, 8), (97, 33, 32, 9)):\n"
         "    L, R, _ = r3d.synth.stereo_pair(W, H, D, seed=seed)\n"
         "    got = r3d.StereoSGBM_create(numDisparities=D, mode=2, **kw).compute(L, R)\n"
         "    want = so.compute(L, R, so.make_params(numDisparities=D, **kw), nthreads=4)\n"
