@@ -2092,6 +2092,8 @@ int launch_vscan2(r3d_ctx *ctx, r3d_sgm_ws &ws, hipStream_t st, const SgmGeom &g
 // stripe and 64 / 32-column tile (2 * SH2 halo columns)
 template <int LPC>
 int launch_vscan3_l(hipStream_t st, const r3d_sgm_ws &ws, const SgmGeom &g, float inv_a, const int *hsum, int16_t *raw, int16_t *mins) {
+    // (4-wave workgroups of 32 columns capped at 128 registers, so that two fit a SIMD beside another kernel's waves, spill 29
+    // registers and measured 3.04 ms against 1.66 ms: profiles/r04_ab_vscan3.log)
     constexpr int NWAVE = 8, CW = 64 / LPC, TC = NWAVE * CW;
     const uint2 *rl = (const uint2 *)ws.rec_l.p, *rr = (const uint2 *)ws.rec_r.p;
 #define R3D_VS3(S)                                                                                                          \
