@@ -8,9 +8,29 @@ import numpy as np
 # HIP maps streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4), in order per queue.  The library pipelines maps over
 # three lanes (own stream each) next to the context stream(s) and the caller's streams: with four queues two of them share one and
 # their kernels serialise -- measured at C2 with three maps in flight: 338-340 maps/s with 4 queues, 365-370 with 8 (16: the same);
-# the 8-view batch on one GPU 31.2-31.6 -> 29.4-29.9 ms.  Read by the HIP runtime when it initialises, i.e. at the first GPU call of
-# the process: set here, at import, unless the user has chosen a value.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# the 8-view batch on one GPU 31.2-31.6 -> 29.4-29.9 ms.  The HIP runtime reads the variable when it initialises, i.e. at the first
+# GPU call of the PROCESS, so it is the application's to set (bench.py and its rank launcher do; INTEGRATION.md recommends it):
+# importing this package does not touch the environment.  The batch entry points warn once when the setting is below what they use.
+RECOMMENDED_ENV = {"GPU_MAX_HW_QUEUES": "8"}
+_warned_queues = False
+
+
+def warn_if_few_hw_queues(streams_in_use):
+    """One warning per process when the batch paths would like more hardware queues than the runtime was started with."""
+    global _warned_queues
+    if _warned_queues:
+        return
+    try:
+        have = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        return
+    if have < streams_in_use:
+        _warned_queues = True
+        import warnings
+        warnings.warn(f"3d_reconstruction_project_amd: {streams_in_use} streams are in use but the HIP runtime maps them onto "
+                      f"GPU_MAX_HW_QUEUES={have} hardware queues (streams that share a queue serialise; measured -8 % on the pipelined "
+                      "batch paths).  Export GPU_MAX_HW_QUEUES=8 before the process makes its first GPU call.", RuntimeWarning, stacklevel=3)
+
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libr3d_hip.so")

@@ -129,6 +129,7 @@ _lib.register({
     "r3d_icp_dev": ([_vp, ctypes.POINTER(_lib.IcpParams), _vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp,
                      ctypes.POINTER(_lib.IcpStats)], ctypes.c_int),
     "r3d_transform_points_dev": ([_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int32, _vp], ctypes.c_int),
+    "r3d_transform_blocks_dev": ([_vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp], ctypes.c_int),
 })
 
 
@@ -453,6 +454,21 @@ def transform_points_device(d_points, n, T, d_out, rotate_only=False, ctx=None):
     ctx = ctx or _lib.default_context()
     T = np.ascontiguousarray(T, dtype=np.float64).reshape(4, 4)
     ctx.call("r3d_transform_points_dev", _vp(d_points), int(n), _ptr(T), int(bool(rotate_only)), _vp(d_out))
+
+
+def transform_blocks_device(blocks, ctx=None):
+    """blocks: sequence of (d_in, n, T 4x4, d_out, rotate_only) -- every block moved by its own rigid transform in one launch per
+    16 blocks (r3d_transform_blocks_dev); device pointers as ints, asynchronous on the context stream."""
+    ctx = ctx or _lib.default_context()
+    nb = len(blocks)
+    if nb == 0:
+        return
+    pin = (ctypes.c_void_p * nb)(*[int(b[0]) for b in blocks])
+    pout = (ctypes.c_void_p * nb)(*[int(b[3]) for b in blocks])
+    cnt = np.ascontiguousarray([int(b[1]) for b in blocks], dtype=np.int64)
+    Ts = np.ascontiguousarray(np.stack([np.asarray(b[2], dtype=np.float64).reshape(4, 4) for b in blocks]))
+    ro = np.ascontiguousarray([1 if b[4] else 0 for b in blocks], dtype=np.int32)
+    ctx.call("r3d_transform_blocks_dev", nb, ctypes.cast(pin, _vp), cnt.ctypes.data_as(_vp), _ptr(Ts), ro.ctypes.data_as(_vp), ctypes.cast(pout, _vp))
 
 
 def backproject_depth(depth, camera, color=None, want_pixels=False, ctx=None):

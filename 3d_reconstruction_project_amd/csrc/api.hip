@@ -125,7 +125,7 @@ void r3d_destroy(r3d_ctx *ctx) {
     for (r3d_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (r3d_sgm_ws &ws : ctx->ws) {
-        r3d_buf *wb[] = {&ws.rec_l, &ws.rec_r, &ws.cost, &ws.cspec, &ws.hsum, &ws.ltop, &ws.ckpt, &ws.raw, &ws.mins, &ws.lrd, &ws.flags, &ws.spk_l, &ws.spk_c};
+        r3d_buf *wb[] = {&ws.rec_l, &ws.rec_r, &ws.cost, &ws.cspec, &ws.hsum, &ws.ltop, &ws.ckpt, &ws.raw, &ws.mins, &ws.lrd, &ws.lrd2, &ws.flags, &ws.spk_l, &ws.spk_c};
         for (r3d_buf *b : wb)
             if (b->p) (void)hipFree(b->p);
         if (ws.ev_created)

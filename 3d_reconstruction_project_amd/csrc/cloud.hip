@@ -1024,6 +1024,7 @@ struct IcpState {
     unsigned long long t_first, t_last;
     int seq;                  // host mirror only: evaluations published so far (written LAST, after a system-scope fence)
 };
+constexpr int ICP_SEQ_DONE = 1 << 30;   // bit of the mirror's `seq` word: the loop has ended (published with the sequence number)
 __device__ __forceinline__ Rigid load_rigid(const IcpState *__restrict__ st) {
     Rigid T;
 #pragma unroll
@@ -1446,31 +1447,49 @@ __device__ __forceinline__ void icp_accumulate(const GridView &g, const double *
                                2.0 - w * (ay * ay + by * by), -w * (ay * az + by * bz), 2.0 - w * (az * az + bz * bz)};
                 double A[6];
                 if (!inv3_sym(M, A)) return;
-                // Jb = [K | I], K = -[p]x ; G = A * Jb (3x6) ; JtJ = Jb^T G ; Jtr = Jb^T (A d)
-                const double K[3][3] = {{0, pz, -py}, {-pz, 0, px}, {py, -px, 0}};
+                // Jb = [K | I], K = -[p]x ; G = A * Jb (3x6) ; JtJ = Jb^T G ; Jtr = Jb^T (A d).
+                // Written out by blocks: K has one zero per row and column and the right half of Jb is the identity; spelled as
+                // dense 3-term products those zeros and ones are real float64 multiplies (0 * x is not foldable under IEEE rules),
+                // a third of this function's arithmetic.  Dropping an exact-zero term of a sum leaves the sum unchanged bit for bit:
+                //   K = [0 pz -py; -pz 0 px; py -px 0],  AK[a][b] = sum_c A[a][c] K[c][b],  JtJ = [K^T A K, K^T A; A K, A]
                 const double As[3][3] = {{A[0], A[1], A[2]}, {A[1], A[3], A[4]}, {A[2], A[4], A[5]}};
-                double G[3][6];
+                double AK[3][3];
 #pragma unroll
                 for (int a = 0; a < 3; a++) {
-#pragma unroll
-                    for (int b = 0; b < 3; b++) {
-                        G[a][b] = As[a][0] * K[0][b] + As[a][1] * K[1][b] + As[a][2] * K[2][b];
-                        G[a][3 + b] = As[a][b];
-                    }
+                    AK[a][0] = As[a][1] * -pz + As[a][2] * py;
+                    AK[a][1] = As[a][0] * pz + As[a][2] * -px;
+                    AK[a][2] = As[a][0] * -py + As[a][1] * px;
                 }
-                double Jb[3][6];
-#pragma unroll
-                for (int a = 0; a < 3; a++)
-#pragma unroll
-                    for (int b = 0; b < 3; b++) { Jb[a][b] = K[a][b]; Jb[a][3 + b] = a == b ? 1.0 : 0.0; }
                 const double Ad[3] = {As[0][0] * dx + As[0][1] * dy + As[0][2] * dz, As[1][0] * dx + As[1][1] * dy + As[1][2] * dz,
                                       As[2][0] * dx + As[2][1] * dy + As[2][2] * dz};
-#pragma unroll
-                for (int a = 0, q = 2; a < 6; a++)
-#pragma unroll
-                    for (int b = a; b < 6; b++, q++) acc[q] += Jb[0][a] * G[0][b] + Jb[1][a] * G[1][b] + Jb[2][a] * G[2][b];
-#pragma unroll
-                for (int a = 0; a < 6; a++) acc[23 + a] += Jb[0][a] * Ad[0] + Jb[1][a] * Ad[1] + Jb[2][a] * Ad[2];
+                // rows of K^T X for a 3-vector of rows X[0..2]: (K^T X)[0] = -pz X[1] + py X[2], [1] = pz X[0] - px X[2], [2] = -py X[0] + px X[1]
+                // slots: q = 2 + index of (a, b), a <= b, row-major over the upper triangle of the 6x6
+                // a = 0: b = 0..5
+                acc[2] += -pz * AK[1][0] + py * AK[2][0];
+                acc[3] += -pz * AK[1][1] + py * AK[2][1];
+                acc[4] += -pz * AK[1][2] + py * AK[2][2];
+                acc[5] += -pz * As[1][0] + py * As[2][0];
+                acc[6] += -pz * As[1][1] + py * As[2][1];
+                acc[7] += -pz * As[1][2] + py * As[2][2];
+                // a = 1: b = 1..5
+                acc[8] += pz * AK[0][1] + -px * AK[2][1];
+                acc[9] += pz * AK[0][2] + -px * AK[2][2];
+                acc[10] += pz * As[0][0] + -px * As[2][0];
+                acc[11] += pz * As[0][1] + -px * As[2][1];
+                acc[12] += pz * As[0][2] + -px * As[2][2];
+                // a = 2: b = 2..5
+                acc[13] += -py * AK[0][2] + px * AK[1][2];
+                acc[14] += -py * As[0][0] + px * As[1][0];
+                acc[15] += -py * As[0][1] + px * As[1][1];
+                acc[16] += -py * As[0][2] + px * As[1][2];
+                // a = 3..5: the rows of A itself
+                acc[17] += As[0][0]; acc[18] += As[0][1]; acc[19] += As[0][2];
+                acc[20] += As[1][1]; acc[21] += As[1][2];
+                acc[22] += As[2][2];
+                acc[23] += -pz * Ad[1] + py * Ad[2];
+                acc[24] += pz * Ad[0] + -px * Ad[2];
+                acc[25] += -py * Ad[0] + px * Ad[1];
+                acc[26] += Ad[0]; acc[27] += Ad[1]; acc[28] += Ad[2];
             }
         }
     
@@ -1530,7 +1549,90 @@ __global__ void __launch_bounds__(ICP_BLOCK, 3) k_icp_eval(GridView g, const dou
     if (threadIdx.x < ICP_SLOTS) {
         double v = 0;
         for (int w2 = 0; w2 < ICP_BLOCK / 64; w2++) v += sm[w2][threadIdx.x];
-        partial[(size_t)blockIdx.x * ICP_SLOTS + threadIdx.x] = v;
+        partial[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = v;   // [slot][workgroup]: the step kernel reads a slot's sums as one contiguous run
+    }
+}
+
+// R3D_ICP_SPLIT=1: the evaluation as TWO kernels.  k_icp_search is k_icp_eval's correspondence search alone -- without the 29
+// float64 accumulators and the Jacobian temporaries it is compiled for four waves per SIMD (k_icp_eval: three) -- and writes the
+// winning target slot per query (4 B; the squared distance is recomputed from it, same expression, so nothing else need travel);
+// k_icp_accum streams queries + slots and runs k_icp_eval's accumulation and reduction with the SAME query -> thread -> workgroup
+// assignment, so the 768 x 29 partial sums are bit for bit those of the fused kernel.
+template <int SEARCH>
+__global__ void __launch_bounds__(ICP_BLOCK, 4) k_icp_search(GridView g, const double *__restrict__ src, int64_t ns, const IcpState *__restrict__ st,
+                                                             double max_dist, int *__restrict__ nn) {
+    __shared__ int sRun[SEARCH == SEARCH_Q10 ? 18 * ICP_BLOCK : 1];
+    if (st->done) return;
+    const Rigid T = load_rigid(st);
+    const double r2 = max_dist * max_dist;
+    const int smax = (int)ceil(max_dist * g.inv_cell);
+    const int64_t nchunk = (ns + ICP_BLOCK - 1) / ICP_BLOCK;
+    int64_t c_begin = blockIdx.x, c_end = nchunk, c_step = gridDim.x;
+    if ((gridDim.x & 7) == 0) {                    // XCD-aware shares: see k_icp_eval
+        const int x = blockIdx.x & 7;
+        c_begin = x * nchunk / 8 + (blockIdx.x >> 3);
+        c_end = (x + 1) * nchunk / 8;
+        c_step = gridDim.x >> 3;
+    }
+    for (int64_t c = c_begin; c < c_end; c += c_step) {
+        const int64_t i = c * ICP_BLOCK + threadIdx.x;
+        if (i >= ns) continue;
+        const double sx = src[i * 3], sy = src[i * 3 + 1], sz = src[i * 3 + 2];
+        const double px = T.r[0] * sx + T.r[1] * sy + T.r[2] * sz + T.t[0];
+        const double py = T.r[3] * sx + T.r[4] * sy + T.r[5] * sz + T.t[1];
+        const double pz = T.r[6] * sx + T.r[7] * sy + T.r[8] * sz + T.t[2];
+        const int cx = cell_coord(px, g.ox, g.inv_cell), cy = cell_coord(py, g.oy, g.inv_cell), cz = cell_coord(pz, g.oz, g.inv_cell);
+        double best = r2;
+        int bi = -1;
+        if (SEARCH == SEARCH_Q10) nn_block_q10(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun);
+        else if (SEARCH == SEARCH_F32) nn_block_top4(g, px, py, pz, cx, cy, cz, best, bi);
+        else nn_block_global(g, px, py, pz, cx, cy, cz, best, bi);
+        nn_outer_shells(g, px, py, pz, cx, cy, cz, smax, best, bi);
+        nn[i] = bi;
+    }
+}
+template <int MODE>
+__global__ void __launch_bounds__(ICP_BLOCK, 3) k_icp_accum(GridView g, const double *__restrict__ src, const double *__restrict__ src_n,
+                                                            const double *__restrict__ tgt_n, int64_t ns, const IcpState *__restrict__ st, double eps,
+                                                            const int *__restrict__ nn, double *__restrict__ partial) {
+    if (st->done) return;
+    const Rigid T = load_rigid(st);
+    double acc[ICP_SLOTS];
+#pragma unroll
+    for (int q = 0; q < ICP_SLOTS; q++) acc[q] = 0;
+    const int64_t nchunk = (ns + ICP_BLOCK - 1) / ICP_BLOCK;
+    int64_t c_begin = blockIdx.x, c_end = nchunk, c_step = gridDim.x;
+    if ((gridDim.x & 7) == 0) {
+        const int x = blockIdx.x & 7;
+        c_begin = x * nchunk / 8 + (blockIdx.x >> 3);
+        c_end = (x + 1) * nchunk / 8;
+        c_step = gridDim.x >> 3;
+    }
+    for (int64_t c = c_begin; c < c_end; c += c_step) {
+        const int64_t i = c * ICP_BLOCK + threadIdx.x;
+        if (i >= ns) continue;
+        const int bi = nn[i];
+        if (bi < 0) continue;
+        const double sx = src[i * 3], sy = src[i * 3 + 1], sz = src[i * 3 + 2];
+        const double px = T.r[0] * sx + T.r[1] * sy + T.r[2] * sz + T.t[0];
+        const double py = T.r[3] * sx + T.r[4] * sy + T.r[5] * sz + T.t[1];
+        const double pz = T.r[6] * sx + T.r[7] * sy + T.r[8] * sz + T.t[2];
+        const double dx = g.pts[(int64_t)bi * 3] - px, dy = g.pts[(int64_t)bi * 3 + 1] - py, dz = g.pts[(int64_t)bi * 3 + 2] - pz;
+        const double best = dx * dx + dy * dy + dz * dz;   // the search's own expression for the winner
+        icp_accumulate<MODE>(g, src_n, tgt_n, i, T, eps, px, py, pz, best, bi, acc);
+    }
+    __shared__ double sm[ICP_BLOCK / 64][ICP_SLOTS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < ICP_SLOTS; q++) {
+        double v = wave_sum(acc[q]);
+        if (lane == 0) sm[wv][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < ICP_SLOTS) {
+        double v = 0;
+        for (int w2 = 0; w2 < ICP_BLOCK / 64; w2++) v += sm[w2][threadIdx.x];
+        partial[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = v;   // [slot][workgroup]: the step kernel reads a slot's sums as one contiguous run
     }
 }
 
@@ -1646,7 +1748,7 @@ __global__ void __launch_bounds__(64) k_icp_eval_t(GridView g, const double *__r
 #pragma unroll
     for (int q = 0; q < ICP_SLOTS; q++) {
         const double v = wave_sum(acc[q]);
-        if (lane == 0) partial[(size_t)blockIdx.x * ICP_SLOTS + q] = v;
+        if (lane == 0) partial[(size_t)q * gridDim.x + blockIdx.x] = v;
     }
 }
 
@@ -1658,6 +1760,32 @@ __global__ void __launch_bounds__(256) k_transform(const double *__restrict__ in
     out[i * 3] = T.r[0] * x + T.r[1] * y + T.r[2] * z + tx;
     out[i * 3 + 1] = T.r[3] * x + T.r[4] * y + T.r[5] * z + ty;
     out[i * 3 + 2] = T.r[6] * x + T.r[7] * y + T.r[8] * z + tz;
+}
+
+// several blocks of triplets, each with its own rigid transform, in ONE launch (the fuse step of the multi-view exchange: eight
+// views x (points, normals) were sixteen launches of ~2 us of work each behind ~18 us of host call overhead each)
+constexpr int TB_MAX = 16;
+struct TransformBlocks {
+    const double *in[TB_MAX];
+    double *out[TB_MAX];
+    long long end[TB_MAX];      // running end offset of block b in the concatenated index space
+    double r[TB_MAX][12];       // row-major 3x3 + translation (zero for rotate-only blocks)
+    int n;
+};
+__global__ void __launch_bounds__(256) k_transform_blocks(TransformBlocks B) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B.end[B.n - 1]) return;
+    int b = 0;
+#pragma unroll
+    for (int q = 0; q < TB_MAX - 1; q++) b += (q < B.n - 1 && i >= B.end[q]) ? 1 : 0;
+    const long long j = i - (b ? B.end[b - 1] : 0);
+    const double *in = B.in[b];
+    double *out = B.out[b];
+    const double *r = B.r[b];
+    const double x = in[j * 3], y = in[j * 3 + 1], z = in[j * 3 + 2];
+    out[j * 3] = r[0] * x + r[1] * y + r[2] * z + r[9];          // the evaluation order of k_transform
+    out[j * 3 + 1] = r[3] * x + r[4] * y + r[5] * z + r[10];
+    out[j * 3 + 2] = r[6] * x + r[7] * y + r[8] * z + r[11];
 }
 
 // ------------------------------------------------------------------------------------------------ disparity -> cloud
@@ -2245,18 +2373,41 @@ __device__ __forceinline__ void icp_publish(const IcpState *st, IcpState *mirror
     mirror->t_first = st->t_first; mirror->t_last = st->t_last;
     mirror->done = st->done;
     __threadfence_system();
-    *(volatile int *)&mirror->seq = st->evals;
+    // the termination travels in the released word itself: a plain `done` store could become visible before the statistics
+    // above, and the host would copy a stale iteration count / fitness (the fields share one 64-byte line)
+    *(volatile int *)&mirror->seq = st->evals | (st->done ? ICP_SEQ_DONE : 0);
 }
 __global__ void __launch_bounds__(1024) k_icp_step(const double *__restrict__ partial, int nblocks, IcpState *__restrict__ st, int64_t ns,
-                                                   int mode, int max_it, double rel_fit, double rel_rmse, IcpState *__restrict__ mirror) {
+                                                   int mode, int max_it, double rel_fit, double rel_rmse, IcpState *__restrict__ mirror,
+                                                   int publish /* this step is one the host waits for (the last step always is) */) {
     __shared__ double sums[32];
     if (st->done) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int slot = w; slot < ICP_SLOTS; slot += 16) {
-        double v = 0;
-        for (int b = lane; b < nblocks; b += 64) v += partial[(size_t)b * ICP_SLOTS + slot];
-        v = wave_sum(v);
-        if (lane == 0) sums[slot] = v;
+    {
+        // wave w owns slots w and w + 16; the partial sums are stored [slot][workgroup], so lane t reads t, t + 64, ... of a
+        // contiguous run, twelve requests per slot in flight (768 workgroups = one round), added in ascending order: the same
+        // sum, bit for bit, as one lane walking them one dependent load at a time (that walk was 2 x 12 L2 round trips of the
+        // 12 us this kernel took)
+        constexpr int U = 12;
+        const int s0 = w, s1 = w + 16;
+        const bool two = s1 < ICP_SLOTS;
+        const double *p0 = partial + (size_t)s0 * nblocks, *p1 = partial + (size_t)(two ? s1 : s0) * nblocks;
+        double v0 = 0, v1 = 0;
+        for (int b0 = 0; b0 < nblocks; b0 += 64 * U) {
+            double a0[U], a1[U];
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const int b = b0 + j * 64 + lane, bc = min(b, nblocks - 1);   // clamped address + select: no branch around a load
+                const double x0 = p0[bc], x1 = p1[bc];
+                a0[j] = b < nblocks ? x0 : 0.0;
+                a1[j] = b < nblocks ? x1 : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < U; j++) { v0 += a0[j]; v1 += a1[j]; }
+        }
+        v0 = wave_sum(v0);
+        v1 = wave_sum(v1);
+        if (lane == 0) { sums[s0] = v0; if (two) sums[s1] = v1; }
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
@@ -2281,7 +2432,7 @@ __global__ void __launch_bounds__(1024) k_icp_step(const double *__restrict__ pa
     for (int i = 0; i < 16; i++) T[i] = st->T[i];
     mat4_mul(U, T, T);
     for (int i = 0; i < 16; i++) st->T[i] = T[i];
-    icp_publish(st, mirror);
+    if (publish) icp_publish(st, mirror);   // (a publish is ~20 posted writes to host memory and a system-scope fence: not once per step)
 }
 
 int upload(r3d_ctx *ctx, DevArena &ar, const double *h, int64_t n3, double **d) {
@@ -2525,6 +2676,10 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
                                    : (int)std::min<int64_t>((ns + ICP_BLOCK - 1) / ICP_BLOCK, (int64_t)std::max(cus, 1) * 3);
     double *d_part = (double *)ar.get((size_t)nblocks * ICP_SLOTS * 8);
     IcpState *d_st = (IcpState *)ar.get(sizeof(IcpState));
+    // R3D_ICP_SPLIT=1: search and accumulation as two kernels (A/B; same partial sums bit for bit)
+    static const bool split_env = [] { const char *e = getenv("R3D_ICP_SPLIT"); return e && !strcmp(e, "1"); }();
+    const bool split_impl = split_env && !tiled_impl;
+    int *d_nn = split_impl ? (int *)ar.get((size_t)ns * 4) : nullptr;
     if (ar.rc) return ar.rc;
     static_assert(sizeof(IcpState) <= ICP_SLOTS * sizeof(double), "the pinned landing buffer holds one IcpState");
     if (!ctx->icp_ev) R3D_HIP(ctx, hipEventCreateWithFlags(&ctx->icp_ev, hipEventDisableTiming));
@@ -2539,7 +2694,7 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
     R3D_HIP(ctx, hipMemcpyAsync(d_st, hst, sizeof *hst, hipMemcpyHostToDevice, ctx->stream));
     const int max_it = p->max_iteration;
     // one evaluation + one step of the loop, enqueued without waiting (both return at once when the loop has ended)
-    auto enqueue_eval = [&]() {
+    auto enqueue_eval = [&](bool publish) {
         const double eps = p->gicp_epsilon > 0 ? p->gicp_epsilon : 1e-3;
         const double md = p->max_correspondence_distance;
         if (tiled_impl) {
@@ -2556,13 +2711,26 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
         case MODE_P2PLANE: R3D_ICP_LAUNCH(MODE_P2PLANE, S); break;  \
         default: R3D_ICP_LAUNCH(MODE_GICP, S); break;               \
     }
+            if (split_impl) {
+                // the search writes one slot per query, so its grid is free: one residency at ITS occupancy (4 workgroups per CU)
+                const int nsearch = (int)std::min<int64_t>((ns + ICP_BLOCK - 1) / ICP_BLOCK, (int64_t)std::max(cus, 1) * 4);
+                if (G.v.q10) k_icp_search<SEARCH_Q10><<<nsearch, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, ns, d_st, md, d_nn);
+                else if (G.v.fx) k_icp_search<SEARCH_F32><<<nsearch, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, ns, d_st, md, d_nn);
+                else k_icp_search<SEARCH_EXACT><<<nsearch, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, ns, d_st, md, d_nn);
+                switch (p->mode) {
+                    case MODE_P2P: k_icp_accum<MODE_P2P><<<nblocks, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, d_st, eps, d_nn, d_part); break;
+                    case MODE_P2PLANE: k_icp_accum<MODE_P2PLANE><<<nblocks, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, d_st, eps, d_nn, d_part); break;
+                    default: k_icp_accum<MODE_GICP><<<nblocks, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, d_st, eps, d_nn, d_part); break;
+                }
+            } else
             if (G.v.q10) { R3D_ICP_MODES(SEARCH_Q10) }
             else if (G.v.fx) { R3D_ICP_MODES(SEARCH_F32) }
             else { R3D_ICP_MODES(SEARCH_EXACT) }
 #undef R3D_ICP_MODES
 #undef R3D_ICP_LAUNCH
         }
-        k_icp_step<<<1, 1024, 0, ctx->stream>>>(d_part, nblocks, d_st, ns, p->mode, max_it, p->relative_fitness, p->relative_rmse, d_mirror);
+        k_icp_step<<<1, 1024, 0, ctx->stream>>>(d_part, nblocks, d_st, ns, p->mode, max_it, p->relative_fitness, p->relative_rmse, d_mirror,
+                                                publish ? 1 : 0);
     };
     R3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const auto t_loop = std::chrono::steady_clock::now();
@@ -2570,16 +2738,26 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
     // time and reads the state back once per batch (a host round trip per iteration cost ~50 us of a 0.22 ms iteration).
     // Polling an event instead of a blocking stream synchronise: the blocking wait may put the thread to sleep for a
     // scheduler tick (occasional 40-50 ms waits).
-    constexpr int ICP_BATCH = 8;
-    for (int enq = 0; enq < max_it + 1;) {
-        for (int b = 0; b < ICP_BATCH && enq < max_it + 1; b++, enq++) enqueue_eval();
+    // A WINDOW of evaluations stays enqueued: ICP_BATCH at first, then ICP_STRIDE more whenever all but ICP_STRIDE of them have
+    // been consumed -- the device never runs dry while the host notices a batch's end and enqueues the next (that hand-over
+    // left the GPU idle for ~40 us per 8 iterations: profiles/r04_icp_timeline.txt).  k_icp_step publishes its state to the
+    // host mirror only at the steps the host waits for (every ICP_STRIDE-th and the last).
+    constexpr int ICP_BATCH = 8, ICP_STRIDE = 4;
+    bool loop_done = false;
+    const int total = max_it + 1;
+    for (int enq = 0; enq < total;) {
+        for (int b = 0, nb = enq == 0 ? ICP_BATCH : ICP_STRIDE; b < nb && enq < total; b++, enq++)
+            enqueue_eval(wait_event || (enq + 1) % ICP_STRIDE == 0 || enq + 1 == total);
         R3D_HIP(ctx, hipGetLastError());
         if (wait_event) {
             R3D_HIP(ctx, hipMemcpyAsync(hst, d_st, sizeof *hst, hipMemcpyDeviceToHost, ctx->stream));
             R3D_HIP(ctx, hipEventRecord(ctx->icp_ev, ctx->stream));
         }
-        // Bounded wait for the batch: either the state k_icp_step publishes in the mapped host buffer (`seq` reaches the number
-        // of evaluations enqueued, or `done`), or (R3D_ICP_WAIT=event) the event behind a D2H copy of the state.  A tight spin for
+        // evaluations that must have been consumed before the host goes on: everything at the end (and in event mode, where
+        // the copy is ordered behind the whole batch), all but the last ICP_STRIDE otherwise
+        const int need = (enq >= total || wait_event) ? enq : enq - ICP_STRIDE;
+        // Bounded wait: either the state k_icp_step publishes in the mapped host buffer (`seq` reaches `need`, or the DONE bit),
+        // or (R3D_ICP_WAIT=event) the event behind a D2H copy of the state.  A tight spin for
         // the first 200 us (a batch of a small cloud is shorter than a sleep), then the thread yields between polls (a bare
         // hipEventQuery spin hammers the runtime's stream lock, which a profiler's completion handlers also need).  The deadline
         // scales with the work enqueued (serialised counter passes are ~100x slower than a plain run); on expiry the call fails
@@ -2592,9 +2770,11 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
                 if (q == hipSuccess) break;
                 if (q != hipErrorNotReady) return r3d_fail(ctx, R3D_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
             } else {
+                // `seq` is the last word k_icp_step stores, behind a system-scope fence: once it shows the awaited step, or the
+                // DONE bit, every other field of that step is visible
                 const int seq = *(volatile int *)&hst->seq;
                 std::atomic_thread_fence(std::memory_order_acquire);
-                if (seq >= enq || (seq > 0 && *(volatile int *)&hst->done)) break;
+                if ((seq & ~ICP_SEQ_DONE) >= need || (seq & ICP_SEQ_DONE)) { loop_done = (seq & ICP_SEQ_DONE) != 0; break; }
             }
             if ((spins & 63) != 63) continue;
             const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_poll).count();
@@ -2605,9 +2785,10 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
             }
             if (waited > 2e-4) std::this_thread::sleep_for(std::chrono::microseconds(waited > 5e-3 ? 200 : 20));
         }
-        if (hst->done) break;
+        if (wait_event) loop_done = hst->done != 0;   // (the copy behind the event is complete: all fields are of one step)
+        if (loop_done) break;
     }
-    if (!hst->done) return r3d_fail(ctx, R3D_E_HIP, "registration loop did not finish (%d evaluations)", hst->evals);
+    if (!loop_done) return r3d_fail(ctx, R3D_E_HIP, "registration loop did not finish (%d evaluations)", hst->evals);
     // (in mirror mode evaluations enqueued behind the step that ended the loop may still be in flight: they return at their first
     // instruction (`done`), and everything this call or the next enqueues is ordered behind them on the same stream)
     memcpy(T, hst->T, sizeof T);
@@ -3432,6 +3613,40 @@ int r3d_transform_points_dev(r3d_ctx *ctx, const double *d_xyz, int64_t n, const
     R3D_HIP(ctx, hipSetDevice(ctx->device));
     k_transform<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(d_xyz, n, to_rigid(T4x4), rotate_only, d_out);
     R3D_HIP(ctx, hipGetLastError());
+    return R3D_OK;
+}
+
+int r3d_transform_blocks_dev(r3d_ctx *ctx, int32_t n_blocks, const double *const *d_xyz, const int64_t *counts, const double *T4x4s,
+                             const int32_t *rotate_only, double *const *d_out) {
+    R3D_ROCTX_RANGE("r3d_transform_blocks_dev");
+    if (!ctx) return R3D_E_BADARG;
+    if (n_blocks < 0 || (n_blocks > 0 && (!d_xyz || !counts || !T4x4s || !d_out))) return r3d_fail(ctx, R3D_E_BADARG, "transform_blocks_dev: bad argument");
+    for (int b = 0; b < n_blocks; b++)
+        if (counts[b] < 0 || (counts[b] > 0 && (!d_xyz[b] || !d_out[b]))) return r3d_fail(ctx, R3D_E_BADARG, "transform_blocks_dev: block %d: bad argument", b);
+    R3D_HIP(ctx, hipSetDevice(ctx->device));
+    for (int b = 0; b < n_blocks;) {
+        TransformBlocks B;
+        B.n = 0;
+        long long end = 0;
+        for (; b < n_blocks && B.n < TB_MAX; b++) {   // the next TB_MAX non-empty blocks
+            if (counts[b] == 0) continue;
+            const double *T = T4x4s + (size_t)b * 16;
+            const bool ro = rotate_only && rotate_only[b];
+            const int q = B.n++;
+            B.in[q] = d_xyz[b];
+            B.out[q] = d_out[b];
+            end += counts[b];
+            B.end[q] = end;
+            for (int i = 0; i < 3; i++) {
+                for (int j = 0; j < 3; j++) B.r[q][i * 3 + j] = T[i * 4 + j];
+                B.r[q][9 + i] = ro ? 0.0 : T[i * 4 + 3];
+            }
+        }
+        if (B.n == 0) continue;
+        for (int q = B.n; q < TB_MAX; q++) { B.in[q] = nullptr; B.out[q] = nullptr; B.end[q] = end; }
+        k_transform_blocks<<<(unsigned)((end + 255) / 256), 256, 0, ctx->stream>>>(B);
+        R3D_HIP(ctx, hipGetLastError());
+    }
     return R3D_OK;
 }
 

@@ -34,7 +34,7 @@ struct r3d_prof_set {
 // the context stream; r3d_sgbm_compute_batch_dev spreads maps over the lanes so that kernels with complementary
 // bottlenecks (cost: VALU + writes, hscan: HBM, vscan: mixed) of consecutive maps overlap.
 struct r3d_sgm_ws {
-    r3d_buf rec_l, rec_r, cost, cspec, hsum, ltop, ckpt, raw, mins, lrd, flags, spk_l, spk_c;
+    r3d_buf rec_l, rec_r, cost, cspec, hsum, ltop, ckpt, raw, mins, lrd, lrd2, flags, spk_l, spk_c;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     hipStream_t aux = nullptr;                       // second stream of the lane: cost slabs ahead of the forward scan

@@ -1684,6 +1684,19 @@ __global__ void __launch_bounds__(256) k_lrcheck(const int16_t *__restrict__ raw
     }
 }
 
+// QUIRK_SMALL_IMAGE_STRIPES (oracle/sgbm3way.c has the derivation): on images so small that a stripe's warm-up start is clamped to
+// row 0 (stripe_sz < overlap: H <= 12 at blockSize 5) the original assembles that stripe's rows from the wrong rows of its private
+// buffer: out[n * stripe_sz + j] = row overlap + j of a run that started at row 0, and rows the run never wrote are uninitialised
+// memory there (the invalid marker here).  `run0` is the LR-checked map of ONE run over the whole image from row 0.
+__global__ void __launch_bounds__(256) k_tiny_assemble(int16_t *__restrict__ lrd, const int16_t *__restrict__ run0, SgmGeom g) {
+    const int x = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (x >= g.W) return;
+    const int n = i / g.stripe_sz;
+    if (n < 1 || n * g.stripe_sz - g.overlap >= 0) return;
+    const int r = g.overlap + (i - n * g.stripe_sz), src_end = min((n + 1) * g.stripe_sz, g.H);
+    lrd[(size_t)i * g.W + x] = r < src_end ? run0[(size_t)r * g.W + x] : (int16_t)g.invalid;
+}
+
 // k_median3: medianBlur(disp, 3) on int16 with replicated borders
 __device__ __forceinline__ void cswap(int &a, int &b) { int lo = min(a, b), hi = max(a, b); a = lo; b = hi; }
 __global__ void __launch_bounds__(256) k_median3(const int16_t *__restrict__ src, int16_t *__restrict__ dst, int W, int H) {
@@ -2182,8 +2195,17 @@ int r3d_selftest_run(r3d_ctx *ctx) {
     return R3D_OK;
 }
 
+// pass 0: the whole call.  pass 1 (only from pass 0, tiny images): ONE run over the whole image from row 0 (a single stripe), up to
+// and including the LR check, its map left in ws.lrd2 -- the rows QUIRK_SMALL_IMAGE_STRIPES hands out in place of a clamped
+// stripe's own.
+static int sgm_run_impl(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p, const uint8_t *d_left, const uint8_t *d_right,
+                        int w, int h, int stride, int16_t *d_disp, int pass);
 int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p, const uint8_t *d_left, const uint8_t *d_right,
                 int w, int h, int stride, int16_t *d_disp) {
+    return sgm_run_impl(ctx, lane, st, p, d_left, d_right, w, h, stride, d_disp, 0);
+}
+static int sgm_run_impl(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p, const uint8_t *d_left, const uint8_t *d_right,
+                        int w, int h, int stride, int16_t *d_disp, int pass) {
     r3d_sgm_ws &ws = ctx->ws[lane];
     if (ctx->poisoned) return r3d_fail(ctx, R3D_E_HIP, "context poisoned by an earlier timed-out call: destroy it");
     SgmGeom g;
@@ -2215,6 +2237,11 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
     if ((rc = r3d_reserve(ctx, ws.raw, npix * 2))) return rc;
     if ((rc = r3d_reserve(ctx, ws.mins, npix * 2))) return rc;
     if ((rc = r3d_reserve(ctx, ws.lrd, npix * 2))) return rc;
+    // R3D_QUIRK_SMALL_IMAGE_STRIPES=0 places every row of a tiny image at its own position (the rounds 1-3 behaviour)
+    static const bool tiny_quirk = [] { const char *e = getenv("R3D_QUIRK_SMALL_IMAGE_STRIPES"); return !(e && !strcmp(e, "0")); }();
+    const bool tiny = pass == 0 && tiny_quirk && g.stripe_sz < h && g.stripe_sz - g.overlap < 0;   // stripe 1 exists and its start is clamped
+    if (pass == 1) g.stripe_sz = h;                    // one stripe: rows [0, h) from row 0 (the other three own no row)
+    if ((tiny || pass == 1) && (rc = r3d_reserve(ctx, ws.lrd2, npix * 2))) return rc;
     ctx->last_w = w; ctx->last_h = h; ctx->last_w1 = g.W1; ctx->last_dp = NPW * 2;
     if ((rc = r3d_reserve(ctx, ws.flags, 256))) return rc;
     r3d_prof_begin(ctx, ws);
@@ -2412,8 +2439,19 @@ int r3d_sgm_run(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_params *p
     }
     }  // impl 1 / 2
     r3d_prof_mark(ctx, ws, st, "lrcheck");
-    k_lrcheck<<<h, 256, (size_t)w * 4, st>>>((const int16_t *)ws.raw.p, (const int16_t *)ws.mins.p, g, (int16_t *)ws.lrd.p);
+    k_lrcheck<<<h, 256, (size_t)w * 4, st>>>((const int16_t *)ws.raw.p, (const int16_t *)ws.mins.p, g, (int16_t *)(pass == 1 ? ws.lrd2.p : ws.lrd.p));
     R3D_HIP(ctx, hipGetLastError());
+    if (pass == 1) return R3D_OK;
+    if (tiny) {
+        // second run (workspaces are reused: this pass's LR-checked map is complete in ws.lrd, stream-ordered), then the assembly
+        const bool prof = ctx->profiling;
+        ctx->profiling = false;
+        rc = sgm_run_impl(ctx, lane, st, p, d_left, d_right, w, h, stride, d_disp, 1);
+        ctx->profiling = prof;
+        if (rc) return rc;
+        k_tiny_assemble<<<dim3((w + 255) / 256, h), 256, 0, st>>>((int16_t *)ws.lrd.p, (const int16_t *)ws.lrd2.p, g);
+        R3D_HIP(ctx, hipGetLastError());
+    }
     r3d_prof_mark(ctx, ws, st, "median3");
     k_median3<<<dim3((w + 255) / 256, h), 256, 0, st>>>((const int16_t *)ws.lrd.p, d_disp, w, h);
     R3D_HIP(ctx, hipGetLastError());

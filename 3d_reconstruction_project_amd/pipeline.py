@@ -249,7 +249,7 @@ def multi_view_fuse_tensors(local, n_views, threshold=0.02, mode=cloud_ops.GICP,
     """BASELINE config C5 on clouds that live where the exchange runs (HBM under RCCL).  local: {view_id: float64 tensor
     [2, n, 3]} (points, normals) of the views this rank owns (distributed.shard_views).  Steps: ONE all-gather-v of the clouds
     (distributed.gather_views) -> every owned view is registered to view 0 (r3d_icp_dev on the gathered blocks, in place) ->
-    the 4x4s are all-gathered -> every view is transformed into the frame of view 0 (r3d_transform_points_dev) into one fused
+    the 4x4s are all-gathered -> every view is transformed into the frame of view 0 (r3d_transform_blocks_dev: one launch) into one fused
     [2, N, 3] tensor, which every rank ends up holding (rank 0 hands it to the mesher, mesh_reconstruction.py:22-37).
     Returns (fused tensor, {view_id: T}).  `register(src [2,n,3], tgt [2,m,3]) -> 4x4` and `transform(block, T) -> block`
     replace the HIP calls in the CPU (gloo) tests; with device tensors and no stubs the HIP library does the work.
@@ -322,14 +322,17 @@ def _multi_view_fuse_on_stream(local, n_views, threshold, mode, max_iteration, r
     total = sum(everyone[v].shape[1] for v in range(n_views))
     fused = torch.empty((2, total, 3), dtype=torch.float64, device=dev)
     o = 0
+    blocks = []
     for v in range(n_views):
         blk, n = everyone[v], everyone[v].shape[1]
         if transform is not None:
             fused[:, o:o + n] = transform(blk, Ts[v])
         elif n:
-            cloud_ops.transform_points_device(blk[0].data_ptr(), n, Ts[v], fused[0, o:o + n].data_ptr(), ctx=ctx)
-            cloud_ops.transform_points_device(blk[1].data_ptr(), n, Ts[v], fused[1, o:o + n].data_ptr(), rotate_only=True, ctx=ctx)
+            blocks.append((blk[0].data_ptr(), n, Ts[v], fused[0, o:o + n].data_ptr(), False))
+            blocks.append((blk[1].data_ptr(), n, Ts[v], fused[1, o:o + n].data_ptr(), True))
         o += n
+    if blocks:       # points and normals of all views in ONE launch (sixteen calls cost 0.3 ms of host overhead, profiles/r03_bench.json)
+        cloud_ops.transform_blocks_device(blocks, ctx=ctx)
     t3 = mark()
     if timings is not None:
         timings.update(exchange_ms=lap(t0, t1), register_ms=lap(t1, t2), fuse_ms=lap(t2, t3))

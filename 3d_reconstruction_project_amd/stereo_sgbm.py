@@ -10,6 +10,7 @@ Same keyword names, defaults, getters/setters and error behaviour (an exception 
 runs in the HIP library (csrc/sgm.hip) through the C ABI in include/r3d.h.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -88,6 +89,8 @@ class StereoSGBM:
         context can wait for it (Context.wait_event) while later maps are still running."""
         n = len(d_lefts)
         assert len(d_rights) == n and len(d_disps) == n and (done_events is None or len(done_events) == n)
+        if n > 1:   # three lanes + the context stream (+ the consumers' streams): more than HIP's default four hardware queues
+            _lib.warn_if_few_hw_queues(int(os.environ.get("R3D_SGM_LANES", "3")) + 2)
         arr = ctypes.c_void_p * n
         p = self.params_struct()
         if done_events is None:

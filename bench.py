@@ -18,6 +18,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Eight hardware queues instead of HIP's four: the pipelined legs keep three SGM lanes, the context stream and the cloud contexts'
+# streams busy at once (INTEGRATION.md "Recommended environment"; +8 % on `pipelined`).  The runtime reads it at the first GPU call
+# of the process, so the application sets it -- here, before anything touches the GPU; the package itself never edits the environment.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 W, H, D = 3264, 2448, 128                     # BASELINE config C2
 C2_KW = dict(minDisparity=0, blockSize=5, P1=8 * 3 * 25, P2=32 * 3 * 25, disp12MaxDiff=1, uniquenessRatio=15,
@@ -343,8 +347,13 @@ def launch_ranks(n, argv):
     import subprocess
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    # The children inherit this process's environment unchanged (plus OMP_NUM_THREADS; GPU_MAX_HW_QUEUES was set at import above).
+    # HSA_ENABLE_IPC_MODE_LEGACY is NOT defaulted here any more: the pool that runs this bench exports it (=0: its host driver
+    # supports dmabuf IPC only, which RCCL's intra-node transport needs), other hosts may need the opposite; say so once if absent.
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver (RCCL needs it)
+    if "HSA_ENABLE_IPC_MODE_LEGACY" not in env:
+        print("bench.py: HSA_ENABLE_IPC_MODE_LEGACY is not set; if RCCL fails with 'hipIpcGetMemHandle: invalid argument' export "
+              "HSA_ENABLE_IPC_MODE_LEGACY=0 (hosts whose driver offers dmabuf IPC only)", file=sys.stderr, flush=True)
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
     print("bench.py: launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)

@@ -311,6 +311,12 @@ int r3d_disparity_to_cloud_resident(r3d_ctx *ctx, const int16_t *d_disp, int32_t
 int r3d_icp_dev(r3d_ctx *ctx, const r3d_icp_params *p, const double *d_src, int64_t ns, const double *d_src_normals, const double *d_tgt,
                 int64_t nt, const double *d_tgt_normals, const double *init4x4, double *T4x4, r3d_icp_stats *stats);
 int r3d_transform_points_dev(r3d_ctx *ctx, const double *d_xyz, int64_t n, const double *T4x4, int32_t rotate_only, double *d_out);
+/* n_blocks device arrays of triplets, block b moved by T4x4s[16 b .. 16 b + 15] (rotation only where rotate_only[b] != 0;
+ * rotate_only may be NULL), in one launch per 16 blocks: the fuse step of the multi-view exchange (every gathered view's points
+ * and normals into view 0's frame before mesh_reconstruction.py:22-37).  Pointer tables and counts are HOST arrays; same
+ * arithmetic as r3d_transform_points_dev; asynchronous on the context stream; d_out[b] may equal d_xyz[b]. */
+int r3d_transform_blocks_dev(r3d_ctx *ctx, int32_t n_blocks, const double *const *d_xyz, const int64_t *counts, const double *T4x4s,
+                             const int32_t *rotate_only, double *const *d_out);
 
 
 /* ---- per-frame stages either side of the matcher in Calib_depth/depth*.py --------------

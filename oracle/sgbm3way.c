@@ -54,6 +54,19 @@ typedef struct {
 
 enum { DISP_SHIFT = 4, DISP_SCALE = 1 << DISP_SHIFT, NSTRIPES = 4 /* QUIRK: fixed, thread-count independent */ };
 
+/* QUIRK_SMALL_IMAGE_STRIPES [recalled, computeDisparity3WAY / SGBM3WayMainLoop::operator()]: every stripe n writes row y of its
+ * run at index dst_offset + (y - src_start) of a PRIVATE buffer of stripe_sz + overlap rows (dst_offset = overlap for n = 0, else
+ * 0), and the map is assembled as out[i] = buffer[i / stripe_sz][overlap + i % stripe_sz].  That is consistent only while
+ * src_start = n * stripe_sz - overlap is not clamped.  On very small images (stripe_sz < overlap: H <= 12 at blockSize 5) a
+ * stripe n >= 1 has n * stripe_sz - overlap < 0: its run starts at row 0 with dst_offset 0, so buffer row r holds the disparity
+ * of IMAGE row r of a run that started at row 0, and the assembly hands out[n * stripe_sz + j] = that run's row (overlap + j) --
+ * a row from further down the image -- while buffer rows at or beyond the stripe's last source row were never written: the
+ * original returns uninitialised memory there.  With the switch on (default) the oracle reproduces the shifted rows and writes
+ * the invalid marker where the original's content is undefined (sgbm_oracle_undefined_rows reports those rows, so a comparison
+ * with the real library can mask them and their median neighbours); off = every row at its own place (rounds 1-3). */
+static int g_quirk_small_image_stripes = 1;
+void sgbm_oracle_set_quirk_small_image_stripes(int on) { g_quirk_small_image_stripes = on != 0; }
+
 #define IMIN(a, b) ((a) < (b) ? (a) : (b))
 #define IMAX(a, b) ((a) > (b) ? (a) : (b))
 
@@ -187,6 +200,9 @@ static int run_stripe(const uint8_t *L, const uint8_t *R, int ldL, int ldR, cons
     const int src_start = IMAX(IMIN(n * g->stripe_sz - g->overlap, H), 0);
     const int src_end = IMIN((n + 1) * g->stripe_sz, H);
     const int out_start = IMIN(n * g->stripe_sz, H); /* rows < out_start only warm the vertical path up */
+    /* QUIRK_SMALL_IMAGE_STRIPES: the run of this stripe was clamped to row 0; computed row y lands at out row y - shift_from */
+    const int shifted = g_quirk_small_image_stripes && n >= 1 && n * g->stripe_sz - g->overlap < 0 && out_start < H;
+    const int out_end = IMIN((n + 1) * g->stripe_sz, H);
     const int hrows = SH2 * 2 + 2;
     const int Dp = D + 2; /* padded path rows */
     const size_t rowN = (size_t)W1 * D;
@@ -234,6 +250,10 @@ static int run_stripe(const uint8_t *L, const uint8_t *R, int ldL, int ldR, cons
 
         for (int x = 0; x < W; x++) { disp2[x] = (int16_t)INVALID; disp2cost[x] = SHRT_MAX; }
         int16_t *drow = (y >= out_start) ? disp + (size_t)y * ldD : NULL;
+        if (shifted) {   /* out[n * stripe_sz + j] = this run's row overlap + j */
+            const int i = out_start + (y - g->overlap);
+            drow = (y >= g->overlap && i < out_end) ? disp + (size_t)i * ldD : NULL;
+        }
 
         /* --- forward pass: L_left (left -> right) and L_top (previous row -> this row, in place) */
         int lmin = 0;
@@ -388,6 +408,22 @@ int sgbm_oracle_compute(const uint8_t *L, const uint8_t *R, int W, int H, int ld
     if (p->speckleWindowSize > 0)
         return sgbm_oracle_filter_speckles(disp, W, H, W, INVALID, p->speckleWindowSize, DISP_SCALE * p->speckleRange);
     return 0;
+}
+
+/* rows of an H-row map whose content is UNDEFINED in the original (QUIRK_SMALL_IMAGE_STRIPES: assembled from stripe-buffer rows
+ * that were never written); mask[i] = 1 for such rows, 0 otherwise.  Returns their number. */
+int sgbm_oracle_undefined_rows(int H, const sgbm_oracle_params *p, uint8_t *mask) {
+    const int stripe_sz = (H + NSTRIPES - 1) / NSTRIPES;
+    const int overlap = (p->blockSize / 2 + 1) + (stripe_sz + 9) / 10;
+    int cnt = 0;
+    for (int i = 0; i < H; i++) {
+        const int n = i / stripe_sz, j = i % stripe_sz;
+        const int src_end = IMIN((n + 1) * stripe_sz, H);
+        const int undef = g_quirk_small_image_stripes && n >= 1 && n * stripe_sz - overlap < 0 && overlap + j >= src_end;
+        if (mask) mask[i] = (uint8_t)undef;
+        cnt += undef;
+    }
+    return cnt;
 }
 
 /* Stage oracle for kernel-level tests: aggregated block cost C(y) of ONE stripe-free row band,

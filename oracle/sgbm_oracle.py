@@ -45,8 +45,25 @@ def lib():
         L.sgbm_oracle_filter_speckles.argtypes = [s16p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_int]
         L.sgbm_oracle_filter_speckles.restype = ctypes.c_int
+        L.sgbm_oracle_set_quirk_small_image_stripes.argtypes = [ctypes.c_int]
+        L.sgbm_oracle_set_quirk_small_image_stripes.restype = None
+        L.sgbm_oracle_undefined_rows.argtypes = [ctypes.c_int, ctypes.POINTER(SgbmParams), u8p]
+        L.sgbm_oracle_undefined_rows.restype = ctypes.c_int
         _lib = L
     return _lib
+
+
+def set_quirk_small_image_stripes(on):
+    """QUIRK_SMALL_IMAGE_STRIPES of sgbm3way.c (default on = [recalled] OpenCV: a stripe whose warm-up start is clamped to row 0
+    hands out rows from further down the image; rows the original leaves uninitialised read INVALID here)."""
+    lib().sgbm_oracle_set_quirk_small_image_stripes(int(bool(on)))
+
+
+def undefined_rows(H, params):
+    """bool [H]: rows whose content is undefined in the original (uninitialised stripe-buffer rows) under the quirk."""
+    m = np.zeros(H, np.uint8)
+    lib().sgbm_oracle_undefined_rows(int(H), ctypes.byref(params), m.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+    return m.astype(bool)
 
 
 def make_params(minDisparity=0, numDisparities=16, blockSize=3, P1=0, P2=0, disp12MaxDiff=0, preFilterCap=0,

@@ -1,7 +1,7 @@
 """Copies the DATA files (no code) that pin the cloud oracle out of the reference's recorded runs.
 Run once in the build container (needs /root/reference); the copies are committed because /root/reference does not
 exist on the GPU box.  Sources:
-  test/output84/  written by test/check84.py:139-191   (voxel 0.02, normals Hybrid r=0.04 max_nn=20)
+  test/output84/  written by test/check84.py:139-191   (voxel 0.02, normals Hybrid r=0.04 max_nn=20); all 76 depth images, clouds 8..11
   test/output/    written by test/check_lama1.py:132-186 (same + SOR(20, 2.0), normals max_nn=30)
   test/dataset/realsense/camera_intrinsic.json  (test/generate_intrinsics.py:28-41)
   Calib_depth/jetson_stereo_8MP_stereo.npz      (Q matrix for disparity -> cloud)
@@ -13,7 +13,7 @@ REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 jobs = []
-for i in range(8, 16):
+for i in range(8, 84):      # the whole recorded scan (76 frames, 6.6 MB): tools/gpu_bench_long_scan.py runs main.py's loop over all of it
     jobs.append((f"test/output84/depth_{i:05d}.png", f"output84/depth_{i:05d}.png"))
 for i in range(8, 12):
     jobs.append((f"test/output84/pcd_{i:05d}.ply", f"output84/pcd_{i:05d}.ply"))

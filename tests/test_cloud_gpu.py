@@ -113,6 +113,32 @@ def test_transform_points(r3d, synth):
     assert np.abs(r3d.cloud_ops.transform_points(p, T, rotate_only=True) - p @ T[:3, :3].T).max() < 1e-14
 
 
+def test_transform_blocks_is_the_per_block_transform_in_one_launch(r3d, synth):
+    """r3d_transform_blocks_dev (the fuse step of the multi-view exchange): 19 ragged blocks incl. an empty one, points and
+    rotate-only normals, in place and out of place -- bit for bit r3d_transform_points_dev block by block (two launches: 16 + 3)."""
+    ctx = r3d.default_context(0)
+    rng = np.random.default_rng(5)
+    sizes = [0 if b == 7 else int(rng.integers(1, 3000)) for b in range(19)]
+    host = [rng.normal(size=(n, 3)) for n in sizes]
+    Ts = [synth.rigid(tuple(rng.normal(size=3)), float(rng.uniform(0, 90)), tuple(rng.normal(size=3))) for _ in sizes]
+    ro = [b % 3 == 1 for b in range(19)]
+    d_in = [ctx.to_device(h) if len(h) else 0 for h in host]
+    d_out = [ctx.alloc(h.nbytes) if len(h) and b % 2 else d_in[b] for b, h in enumerate(host)]      # even blocks in place
+    want = [r3d.cloud_ops.transform_points(h, T, rotate_only=r) if len(h) else h for h, T, r in zip(host, Ts, ro)]
+    r3d.cloud_ops.transform_blocks_device([(d_in[b], sizes[b], Ts[b], d_out[b], ro[b]) for b in range(19)], ctx=ctx)
+    for b in range(19):
+        if sizes[b] == 0:
+            continue
+        got = np.empty_like(host[b])
+        ctx.d2h(got, d_out[b])
+        assert np.array_equal(got, want[b]), b
+    for b in range(19):
+        if sizes[b]:
+            ctx.free(d_in[b])
+            if d_out[b] != d_in[b]:
+                ctx.free(d_out[b])
+
+
 def _sphere(n, seed, r=1.0):
     rng = np.random.default_rng(seed)
     v = rng.standard_normal((n, 3))

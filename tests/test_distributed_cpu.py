@@ -1,5 +1,6 @@
-"""world_size-2 (and 3) gloo tests of the exchange step and of the sharded multi-view fusion logic (no GPU:
-the HIP registration is replaced by an injected stub; the exchange code path is the one the GPUs run)."""
+"""gloo tests of the exchange step and of the sharded multi-view fusion logic at world sizes 2, 3, 4 and 8 -- 8 ranks with one
+view each is the topology of BASELINE config C5 -- (no GPU: the HIP registration is replaced by an injected stub; the exchange
+code path is the one the GPUs run)."""
 import os
 import socket
 import sys
@@ -96,7 +97,7 @@ def _worker(rank, world, port, n_views, q):
         q.put((rank, "fail", traceback.format_exc() + str(e)))
 
 
-@pytest.mark.parametrize("world,n_views", [(2, 8), (3, 5)])
+@pytest.mark.parametrize("world,n_views", [(2, 8), (3, 5), (4, 8), (8, 8)])
 def test_exchange_and_sharded_fusion_gloo(world, n_views):
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -105,7 +106,7 @@ def test_exchange_and_sharded_fusion_gloo(world, n_views):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_views, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in range(world)]
+    res = [q.get(timeout=420) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res

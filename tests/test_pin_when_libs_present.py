@@ -26,6 +26,20 @@ def test_sgbm_oracle_equals_cv2(W, H, D, kw):
     np.testing.assert_array_equal(so.compute(L, R, so.make_params(numDisparities=D, **kw), nthreads=4), m.compute(L, R))
 
 
+def test_sgbm_oracle_small_image_stripes_equal_cv2():
+    """QUIRK_SMALL_IMAGE_STRIPES: a 12-row image (stripe_sz 3 < overlap 4).  Rows the original assembles from never-written
+    stripe-buffer rows are uninitialised memory there: they, and the rows the 3x3 median mixes them into, are masked."""
+    cv2 = pytest.importorskip("cv2")
+    from oracle import sgbm_oracle as so
+    L, R, _ = synth.stereo_pair(200, 12, 16, seed=3)
+    prm = so.make_params(numDisparities=16, **C2_KW)
+    undef = so.undefined_rows(12, prm)
+    keep = ~(undef | np.roll(undef, 1) | np.roll(undef, -1))
+    got = so.compute(L, R, prm, nthreads=4)
+    want = cv2.StereoSGBM_create(numDisparities=16, mode=cv2.STEREO_SGBM_MODE_SGBM_3WAY, **C2_KW).compute(L, R)
+    np.testing.assert_array_equal(got[keep], want[keep])
+
+
 def test_filter_speckles_oracle_equals_cv2():
     cv2 = pytest.importorskip("cv2")
     from oracle import sgbm_oracle as so

@@ -245,10 +245,22 @@ def test_row_stride_larger_than_width(r3d, synth):
         m.compute_device(1, 1, W, H, W - 1, 1)                      # stride < width is refused before any access
 
 
-@pytest.mark.parametrize("W,H,D", [(17, 1, 16), (18, 2, 16), (33, 3, 32), (16, 5, 16), (40, 2, 32)])
+@pytest.mark.parametrize("W,H,D", [(17, 1, 16), (18, 2, 16), (33, 3, 32), (16, 5, 16), (40, 2, 32), (60, 12, 16), (50, 9, 16), (70, 11, 32)])
 def test_tiny_images_bit_exact(r3d, W, H, D):
-    """Images of one to five rows and a matching range of zero to a few columns (W - D = 1, 2, 1, 0, 8)."""
+    """Images of one to twelve rows and a matching range of zero to a few columns.  H <= 12 at blockSize 5 is where a stripe's
+    warm-up start is clamped to row 0 and QUIRK_SMALL_IMAGE_STRIPES (oracle/sgbm3way.c) moves rows: the product reproduces the
+    oracle's placement, invalid marker for the rows the original leaves uninitialised included."""
     rng = np.random.default_rng(W * H)
     L = rng.integers(0, 256, (H, W), dtype=np.uint8)
     R = rng.integers(0, 256, (H, W), dtype=np.uint8)
     np.testing.assert_array_equal(_gpu(r3d, D, C2_KW).compute(L, R), _oracle(L, R, D, C2_KW))
+
+
+def test_tiny_image_stripe_quirk_with_large_blocks(r3d):
+    """blockSize 11: stripe_sz 6 < overlap 7 at H = 24 (the quirk), regular at H = 28; both against the oracle, raw map included."""
+    from oracle import sgbm_oracle as so
+    kw = dict(minDisparity=0, blockSize=11, P1=100, P2=1000, disp12MaxDiff=1, uniquenessRatio=5, speckleWindowSize=0, speckleRange=2, preFilterCap=31)
+    for H in (24, 28, 21):
+        L, R, _ = r3d.synth.stereo_pair(120, H, 32, seed=H)
+        assert so.undefined_rows(H, so.make_params(numDisparities=32, **kw)).any() == (H <= 24)
+        np.testing.assert_array_equal(_gpu(r3d, 32, kw).compute(L, R), _oracle(L, R, 32, kw))

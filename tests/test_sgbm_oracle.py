@@ -100,3 +100,30 @@ def test_oracle_empty_matching_range_is_an_all_invalid_map():
     L = np.random.default_rng(0).integers(0, 256, (9, 100), dtype=np.uint8)
     d, raw = so.compute(L, L, so.make_params(numDisparities=112, blockSize=5, P1=600, P2=2400, preFilterCap=63), return_raw=True)
     assert (d == -16).all() and (raw == -16).all()
+
+
+def test_quirk_small_image_stripes_shifts_clamped_stripes():
+    """QUIRK_SMALL_IMAGE_STRIPES ([recalled] computeDisparity3WAY: private stripe buffers + assembly from row overlap + i % stripe_sz).
+    H = 12, blockSize 5: stripe_sz 3, overlap 4; stripe 1 (rows 3-5) would start at row -1, is clamped to 0 with dst_offset 0, and
+    the assembly hands out its run's rows 4, 5 and a row that was never written.  Stripes 2 and 3 (start 2, 5) are regular.  With the
+    quirk OFF stripe 1's run also starts at row 0 and writes its own rows, so its rows 4, 5 are exactly what the quirk shifts up."""
+    rng = np.random.default_rng(4)
+    L = rng.integers(0, 256, (12, 60), dtype=np.uint8)
+    R = np.roll(L, -5, axis=1)
+    prm = so.make_params(numDisparities=16, blockSize=5, P1=600, P2=2400, disp12MaxDiff=1, uniquenessRatio=15, preFilterCap=63)
+    try:
+        so.set_quirk_small_image_stripes(False)
+        _, off = so.compute(L, R, prm, return_raw=True)
+        assert not so.undefined_rows(12, prm).any()
+        so.set_quirk_small_image_stripes(True)
+        d_on, on = so.compute(L, R, prm, return_raw=True)
+        assert list(np.nonzero(so.undefined_rows(12, prm))[0]) == [5]
+    finally:
+        so.set_quirk_small_image_stripes(True)
+    assert np.array_equal(on[[0, 1, 2, 6, 7, 8, 9, 10, 11]], off[[0, 1, 2, 6, 7, 8, 9, 10, 11]])
+    assert np.array_equal(on[3], off[4]) and np.array_equal(on[4], off[5]) and (on[5] == -16).all()
+    assert (off[3:6, 16:] != -16).any()                         # the rows that move do hold disparities
+    # a regular image is untouched by the switch, and blockSize 11 reaches the quirk at H = 24 (stripe_sz 6 < overlap 7)
+    prm11 = so.make_params(numDisparities=16, blockSize=11, P1=100, P2=1000, preFilterCap=31)
+    assert list(np.nonzero(so.undefined_rows(24, prm11))[0]) == [11] and not so.undefined_rows(28, prm11).any()
+    assert not so.undefined_rows(13, prm).any() and not so.undefined_rows(2448, prm).any()

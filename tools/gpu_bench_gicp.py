@@ -14,4 +14,5 @@ for mode, name in ((co.GICP, "gicp"), (co.P2PLANE, "p2plane"), (co.P2P, "p2p")):
         continue
     for rep in range(4):
         res = co.registration(src, tgt, 0.02, mode=mode, max_iteration=20, relative_fitness=-1, relative_rmse=-1, source_normals=sn, target_normals=tn)
-        print(name, rep, "loop_ms", round(res["loop_ms"], 3), "per iter", round(res["loop_ms"] / 21, 4), "setup", round(res["setup_ms"], 2), "err", float(np.linalg.norm(res["T"] - T_star)), flush=True)
+        print(name, rep, "loop_ms", round(res["loop_ms"], 3), "per iter", round(res["loop_ms"] / 21, 4), "setup", round(res["setup_ms"], 2), "err", float(np.linalg.norm(res["T"] - T_star)),
+              "T_sha", __import__("hashlib").sha1(np.ascontiguousarray(res["T"]).tobytes()).hexdigest()[:12], "rmse", repr(res["inlier_rmse"]), flush=True)
