@@ -117,6 +117,7 @@ _lib.register({
     "r3d_model_destroy": ([_vp], None),
     "r3d_model_clear": ([_vp], ctypes.c_int),
     "r3d_model_size": ([_vp, _i64p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)], ctypes.c_int),
+    "r3d_model_voxel_table_stats": ([_vp, _i64p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)], ctypes.c_int),
     "r3d_model_append": ([_vp, _vp, _vp, _vp, ctypes.c_int64], ctypes.c_int),
     "r3d_model_align_append": ([_vp, ctypes.POINTER(AlignParams), _vp, _vp, ctypes.c_int64, _vp, ctypes.POINTER(_lib.IcpStats), _i64p],
                                ctypes.c_int),
@@ -348,6 +349,12 @@ class ResidentModel:
 
     def __len__(self):
         return self.size()[0]
+
+    def voxel_table_stats(self):
+        """(voxels in the resident legacy voxel table, full rebuilds, incremental updates) -- r3d_model_voxel_table_stats."""
+        v, r, u = ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32()
+        self._call("r3d_model_voxel_table_stats", ctypes.byref(v), ctypes.byref(r), ctypes.byref(u))
+        return v.value, r.value, u.value
 
     def clear(self):
         self._call("r3d_model_clear")

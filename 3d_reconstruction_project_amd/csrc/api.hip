@@ -300,12 +300,21 @@ int r3d_sgbm_compute_batch_events_dev(r3d_ctx *ctx, const r3d_sgbm_params *p, in
     for (int i = 0; i < n && rc == R3D_OK; i++) {
         const int l = i % lanes;
         rc = r3d_sgm_run(ctx, l, ctx->ws[l].stream, p, d_left[i], d_right[i], w, h, stride, d_disp[i]);
-        if (rc == R3D_OK && done_events && done_events[i]) R3D_HIP(ctx, hipEventRecord((hipEvent_t)done_events[i], ctx->ws[l].stream));
+        if (rc == R3D_OK && done_events && done_events[i]) {
+            // a stale or foreign-device event handle fails here: remember it, stop launching, and STILL run the join below
+            const hipError_t e = hipEventRecord((hipEvent_t)done_events[i], ctx->ws[l].stream);
+            if (e != hipSuccess) rc = r3d_fail(ctx, R3D_E_HIP, "sgbm batch: recording done_events[%d] failed: %s", i, hipGetErrorString(e));
+        }
     }
-    // join: the context stream continues after every lane has drained
+    // join: the context stream continues after every lane has drained -- on EVERY exit path after the fork, so that maps already
+    // enqueued on the lanes stay ordered before whatever the caller queues next on the context stream
     for (int l = 0; l < lanes; l++) {
-        R3D_HIP(ctx, hipEventRecord(ctx->ws[l].done, ctx->ws[l].stream));
-        R3D_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ws[l].done, 0));
+        hipError_t e = hipEventRecord(ctx->ws[l].done, ctx->ws[l].stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ws[l].done, 0);
+        if (e != hipSuccess) {                 // cannot order the lane by an event: drain it on the host instead
+            (void)hipStreamSynchronize(ctx->ws[l].stream);
+            if (rc == R3D_OK) rc = r3d_fail(ctx, R3D_E_HIP, "sgbm batch: joining lane %d failed: %s", l, hipGetErrorString(e));
+        }
     }
     return rc;
 }

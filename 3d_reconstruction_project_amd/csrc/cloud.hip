@@ -1857,6 +1857,114 @@ __global__ void __launch_bounds__(256) k_backproject(const unsigned short *__res
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// ------------------------------------------------------------------------------------------------ incremental model voxel table
+// The scanning loop re-down-samples the WHOLE model every frame (pointcloud_alignment.py:23; main.py:48).  The legacy grid's voxel
+// of a point depends only on the model's minimum corner (origin = min_bound - voxel / 2) and a voxel's mean is its members summed
+// in index order, so while the minimum corner stays put, a frame appended at the END of the model only continues running sums:
+// the table keeps, per occupied voxel in lexicographic (kx, ky, kz) order, the packed key, the running float64 sums and the
+// count; a new frame's points are sorted by (voxel, index), every run is added member by member onto its voxel's running sum
+// (or starts a new voxel from zero), and the new voxels are merged into the sorted table.  means = sums / count are then bit for
+// bit those of a full re-voxelisation (tests/test_pipeline_gpu.py asserts it; R3D_MODEL_IMPL=rebuild keeps the full pass).
+__device__ __forceinline__ unsigned long long vt_key_of(const double *__restrict__ p, double ox, double oy, double oz, double voxel) {
+    const long long kx = (long long)floor((p[0] - ox) / voxel), ky = (long long)floor((p[1] - oy) / voxel), kz = (long long)floor((p[2] - oz) / voxel);
+    return (unsigned long long)kx << 42 | (unsigned long long)ky << 21 | (unsigned long long)kz;   // each index < 2^21 (checked on the host)
+}
+// table from scratch: one thread per voxel segment of the (voxel, index)-sorted model (the loop of k_voxel_mean_sorted)
+template <int R>
+__global__ void __launch_bounds__(256) k_vt_build(const double *__restrict__ sp, const int *__restrict__ starts, int64_t nseg, int64_t n, double ox,
+                                                  double oy, double oz, double voxel, unsigned long long *__restrict__ keys,
+                                                  double *__restrict__ sums, int *__restrict__ cnt) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= nseg) return;
+    const int b = starts[s], e = s + 1 < nseg ? starts[s + 1] : (int)n, m = e - b;
+    const double *__restrict__ p = sp + (int64_t)b * 3;
+    double x = 0, y = 0, z = 0;
+    double cur[3 * R], nxt[3 * R];
+#pragma unroll
+    for (int u = 0; u < R; u++) {
+        const int64_t q = (int64_t)min(u, m - 1) * 3;
+        cur[u * 3] = p[q]; cur[u * 3 + 1] = p[q + 1]; cur[u * 3 + 2] = p[q + 2];
+    }
+    keys[s] = vt_key_of(cur, ox, oy, oz, voxel);
+    for (int i0 = 0; i0 < m; i0 += R) {
+#pragma unroll
+        for (int u = 0; u < R; u++) {
+            const int64_t q = (int64_t)min(i0 + R + u, m - 1) * 3;
+            nxt[u * 3] = p[q]; nxt[u * 3 + 1] = p[q + 1]; nxt[u * 3 + 2] = p[q + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < R; u++)
+            if (i0 + u < m) { x += cur[u * 3]; y += cur[u * 3 + 1]; z += cur[u * 3 + 2]; }
+#pragma unroll
+        for (int u = 0; u < 3 * R; u++) cur[u] = nxt[u];
+    }
+    sums[s * 3] = x; sums[s * 3 + 1] = y; sums[s * 3 + 2] = z;
+    cnt[s] = m;
+}
+__device__ __forceinline__ int64_t vt_lower_bound(const unsigned long long *__restrict__ keys, int64_t n, unsigned long long k) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < k) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// one thread per run of the sorted slice: continue the voxel's running sum in place, or start a new voxel
+__global__ void __launch_bounds__(256) k_vt_update(const double *__restrict__ sp, const int *__restrict__ starts, int64_t nseg, int64_t n, double ox,
+                                                   double oy, double oz, double voxel, const unsigned long long *__restrict__ tkeys, int64_t tn,
+                                                   double *__restrict__ tsums, int *__restrict__ tcnt, unsigned long long *__restrict__ segkey,
+                                                   int *__restrict__ is_new, int64_t *__restrict__ ins, double *__restrict__ nsum, int *__restrict__ ncnt) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= nseg) return;
+    const int b = starts[s], e = s + 1 < nseg ? starts[s + 1] : (int)n;
+    const double *__restrict__ p = sp + (int64_t)b * 3;
+    const unsigned long long k = vt_key_of(p, ox, oy, oz, voxel);
+    const int64_t pos = vt_lower_bound(tkeys, tn, k);
+    const bool found = pos < tn && tkeys[pos] == k;
+    double x = 0, y = 0, z = 0;
+    if (found) { x = tsums[pos * 3]; y = tsums[pos * 3 + 1]; z = tsums[pos * 3 + 2]; }
+    for (int i = 0; i < e - b; i++) { x += p[(int64_t)i * 3]; y += p[(int64_t)i * 3 + 1]; z += p[(int64_t)i * 3 + 2]; }
+    segkey[s] = k;
+    is_new[s] = found ? 0 : 1;
+    ins[s] = pos;
+    if (found) {
+        tsums[pos * 3] = x; tsums[pos * 3 + 1] = y; tsums[pos * 3 + 2] = z;
+        tcnt[pos] += e - b;
+    } else {
+        nsum[s * 3] = x; nsum[s * 3 + 1] = y; nsum[s * 3 + 2] = z;
+        ncnt[s] = e - b;
+    }
+}
+// merge: old voxel i moves up by the number of NEW keys below it; new voxel s goes to (old keys below it) + (new keys below it)
+__global__ void __launch_bounds__(256) k_vt_merge(const unsigned long long *__restrict__ tkeys, const double *__restrict__ tsums, const int *__restrict__ tcnt,
+                                                  int64_t tn, const unsigned long long *__restrict__ segkey, const int *__restrict__ is_new,
+                                                  const int *__restrict__ rank /* exclusive scan of is_new */, const int64_t *__restrict__ ins,
+                                                  const double *__restrict__ nsum, const int *__restrict__ ncnt, int64_t nseg, int total_new,
+                                                  unsigned long long *__restrict__ okeys, double *__restrict__ osums, int *__restrict__ ocnt) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < tn) {
+        const unsigned long long k = tkeys[i];
+        const int64_t lb = vt_lower_bound(segkey, nseg, k);          // runs with a smaller key
+        const int64_t pos = i + (lb < nseg ? rank[lb] : total_new);
+        okeys[pos] = k;
+        osums[pos * 3] = tsums[i * 3]; osums[pos * 3 + 1] = tsums[i * 3 + 1]; osums[pos * 3 + 2] = tsums[i * 3 + 2];
+        ocnt[pos] = tcnt[i];
+    } else if (i < tn + nseg) {
+        const int64_t s = i - tn;
+        if (!is_new[s]) return;
+        const int64_t pos = ins[s] + rank[s];
+        okeys[pos] = segkey[s];
+        osums[pos * 3] = nsum[s * 3]; osums[pos * 3 + 1] = nsum[s * 3 + 1]; osums[pos * 3 + 2] = nsum[s * 3 + 2];
+        ocnt[pos] = ncnt[s];
+    }
+}
+__global__ void __launch_bounds__(256) k_vt_means(const double *__restrict__ sums, const int *__restrict__ cnt, int64_t n, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double c = (double)cnt[i];
+    out[i * 3] = sums[i * 3] / c; out[i * 3 + 1] = sums[i * 3 + 1] / c; out[i * 3 + 2] = sums[i * 3 + 2] / c;
+}
+
 struct DevArena {  // simple bump allocator over ctx->cloud_bufs (grow-only, reused across calls)
     r3d_ctx *ctx;
     size_t next = 0;
@@ -2184,11 +2292,13 @@ int grid_build(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, doubl
     // two-level cell table from the sorted keys (GridView::l1 / l2); sized for the worst case, only materialised lines are touched
     const int64_t nl = ((G.ncells + CL_STRIDE) >> CL_SHIFT) + 1;
     const int64_t max_lines = std::min<int64_t>(nl, 2 * n + 1);
-    int *mark = (int *)ar.get((size_t)nl * 4 * 2), *last1 = mark + nl;      // one fill zeroes both
+    // one fill zeroes both; last1 starts at a multiple of four ints so that the scans' 16-byte accesses stay aligned
+    const int64_t nl4 = (nl + 3) & ~(int64_t)3;
+    int *mark = (int *)ar.get((size_t)(nl4 + nl) * 4), *last1 = mark + nl4;
     int *ids = (int *)ar.get((size_t)nl * 4), *before = (int *)ar.get((size_t)nl * 4), *l1 = (int *)ar.get((size_t)nl * 4);
     int *l2 = (int *)ar.get((size_t)(max_lines + 1) * CL_STRIDE * 4);
     if (ar.rc) return ar.rc;
-    R3D_HIP(ctx, hipMemsetAsync(mark, 0, (size_t)nl * 4 * 2, ctx->stream));
+    R3D_HIP(ctx, hipMemsetAsync(mark, 0, (size_t)(nl4 + nl) * 4, ctx->stream));
     const int nb = (int)((n + 255) / 256), nlb = (int)((nl + 255) / 256);
     if (G.keys32) k_line_mark<unsigned><<<nb, 256, 0, ctx->stream>>>((const unsigned *)G.keys, n, mark, last1);
     else k_line_mark<unsigned long long><<<nb, 256, 0, ctx->stream>>>((const unsigned long long *)G.keys, n, mark, last1);
@@ -2533,10 +2643,19 @@ struct VoxelSegs {
     double *sorted = nullptr;   // the points in (voxel, index) order (written by the sort)
     int64_t nseg = 0;
 };
-int voxel_segments(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, double voxel, VoxelSegs &V, bool tensor_grid = false) {
+// fixed_org / fixed_max (legacy grid only): use this origin and size the key space for points up to fixed_max instead of deriving
+// both from the cloud's own bounding box (the incremental model table: a slice of the model keyed in the MODEL's grid; no
+// bounding-box pass).  bounds_out[6] receives min / max of the cloud when its box was computed here.
+int voxel_segments(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, double voxel, VoxelSegs &V, bool tensor_grid = false,
+                   const double *fixed_org = nullptr, const double *fixed_max = nullptr, double *bounds_out = nullptr) {
     double mn[3], mx[3];
     int rc;
-    if ((rc = cloud_bbox(ctx, ar, d_p, n, mn, mx))) return rc;
+    if (fixed_org) {
+        for (int a = 0; a < 3; a++) { mn[a] = fixed_org[a] + 0.5 * voxel; mx[a] = fixed_max[a]; }
+    } else {
+        if ((rc = cloud_bbox(ctx, ar, d_p, n, mn, mx))) return rc;
+        if (bounds_out) for (int a = 0; a < 3; a++) { bounds_out[a] = mn[a]; bounds_out[3 + a] = mx[a]; }
+    }
     double org[3];
     int dims[3];
     double total = 1;
@@ -2547,7 +2666,7 @@ int voxel_segments(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, dou
             org[a] = k0;
             dims[a] = (int)(k1 - k0) + 1;
         } else {
-            org[a] = mn[a] - 0.5 * voxel;  // legacy: voxel_min_bound = min_bound - voxel_size * 0.5
+            org[a] = fixed_org ? fixed_org[a] : mn[a] - 0.5 * voxel;  // legacy: voxel_min_bound = min_bound - voxel_size * 0.5
             dims[a] = (int)std::floor((mx[a] - org[a]) / voxel) + 2;
         }
         total *= dims[a];
@@ -3285,6 +3404,14 @@ struct r3d_model {
     r3d_buf pts, cols, nrms;
     int64_t n = 0;
     bool has_colors = false, has_normals = false;
+    // incremental legacy voxel table of the model's points (k_vt_*): valid for voxel size vt_voxel while the model's minimum
+    // corner is vt_min; covers model rows [0, vt_pts); vt_n voxels in buffers [vt_cur] (double-buffered for the merge)
+    bool vt_valid = false;
+    double vt_voxel = 0, vt_min[3] = {0, 0, 0}, vt_max[3] = {0, 0, 0};
+    int64_t vt_n = 0, vt_pts = 0;
+    r3d_buf vt_keys[2], vt_sums[2], vt_cnt[2];
+    int vt_cur = 0;
+    int vt_rebuilds = 0, vt_updates = 0;   // statistics (r3d_model_voxel_table_stats)
 };
 namespace {
 // grows a model buffer to hold `rows` triplets, keeping the first `keep` rows
@@ -3342,7 +3469,7 @@ void r3d_model_destroy(r3d_model *m) {
     if (!m) return;
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
-    for (r3d_buf *b : {&m->pts, &m->cols, &m->nrms})
+    for (r3d_buf *b : {&m->pts, &m->cols, &m->nrms, &m->vt_keys[0], &m->vt_keys[1], &m->vt_sums[0], &m->vt_sums[1], &m->vt_cnt[0], &m->vt_cnt[1]})
         if (b->p) (void)hipFree(b->p);
     delete m;
 }
@@ -3351,6 +3478,8 @@ int r3d_model_clear(r3d_model *m) {
     if (!m) return R3D_E_BADARG;
     m->n = 0;
     m->has_colors = m->has_normals = false;
+    m->vt_valid = false;
+    m->vt_n = m->vt_pts = 0;
     return R3D_OK;
 }
 
@@ -3359,6 +3488,14 @@ int r3d_model_size(r3d_model *m, int64_t *n, int32_t *has_colors, int32_t *has_n
     if (n) *n = m->n;
     if (has_colors) *has_colors = m->has_colors;
     if (has_normals) *has_normals = m->has_normals;
+    return R3D_OK;
+}
+
+int r3d_model_voxel_table_stats(r3d_model *m, int64_t *voxels, int32_t *rebuilds, int32_t *updates) {
+    if (!m) return R3D_E_BADARG;
+    if (voxels) *voxels = m->vt_valid ? m->vt_n : 0;
+    if (rebuilds) *rebuilds = m->vt_rebuilds;
+    if (updates) *updates = m->vt_updates;
     return R3D_OK;
 }
 
@@ -3374,6 +3511,118 @@ int r3d_model_append(r3d_model *m, const double *xyz, const double *colors, cons
 
 }  // extern "C"
 namespace {
+// grow-only table buffer for `rows` voxels
+int vt_reserve(r3d_model *m, r3d_buf &b, int64_t rows, size_t elem) {
+    const size_t bytes = (size_t)rows * elem;
+    if (bytes <= b.cap) return R3D_OK;
+    const size_t want = bytes + bytes / 2 + 4096;
+    if (b.p) { (void)hipStreamSynchronize(m->ctx->stream); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) { b.p = nullptr; return r3d_fail(m->ctx, R3D_E_OOM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+    b.cap = want;
+    return R3D_OK;
+}
+// pointcloud_alignment.py:23 for the resident model: the legacy voxel grid of ALL model points, as means in lexicographic voxel
+// order in a fresh arena buffer.  Default: the incremental table above (full rebuild whenever the model's minimum corner moved, the
+// voxel size changed or the table does not exist); R3D_MODEL_IMPL=rebuild: the full sort of every model point, every frame.
+int model_target_voxels(r3d_model *m, DevArena &ar, double voxel, double **d_tv_out, int64_t *mt_out) {
+    r3d_ctx *ctx = m->ctx;
+    int rc;
+    double *d_t = (double *)m->pts.p;
+    static const bool always_rebuild = [] { const char *e = getenv("R3D_MODEL_IMPL"); return e && !strcmp(e, "rebuild"); }();
+    if (always_rebuild) {
+        VoxelSegs Vt;
+        if ((rc = voxel_segments(ctx, ar, d_t, m->n, voxel, Vt))) return rc;
+        double *d_tv = (double *)ar.get((size_t)Vt.nseg * 24);
+        if (ar.rc) return ar.rc;
+        if ((rc = launch_voxel_mean(ctx, ar, false, d_t, Vt.idx, Vt.starts, Vt.nseg, m->n, d_tv, Vt.sorted))) return rc;
+        *d_tv_out = d_tv;
+        *mt_out = Vt.nseg;
+        return R3D_OK;
+    }
+    bool rebuild = !m->vt_valid || m->vt_voxel != voxel || m->vt_pts > m->n;
+    const int64_t ns = m->n - m->vt_pts;
+    double smn[3], smx[3];
+    if (!rebuild && ns > 0) {
+        if ((rc = cloud_bbox(ctx, ar, d_t + m->vt_pts * 3, ns, smn, smx))) return rc;
+        for (int a = 0; a < 3; a++) if (smn[a] < m->vt_min[a]) rebuild = true;   // the grid origin moves: every key changes
+    }
+    auto key_space_ok = [&](const double *mn, const double *mx) {
+        for (int a = 0; a < 3; a++) if (!((mx[a] - (mn[a] - 0.5 * voxel)) / voxel < 2097000.0)) return false;
+        return true;
+    };
+    const unsigned long long *tkeys = nullptr;
+    if (rebuild) {
+        VoxelSegs Vt;
+        double bounds[6];
+        if ((rc = voxel_segments(ctx, ar, d_t, m->n, voxel, Vt, false, nullptr, nullptr, bounds))) return rc;
+        if (!key_space_ok(bounds, bounds + 3)) {          // more than 2^21 voxels along an axis: no table, the plain full pass
+            m->vt_valid = false;
+            double *d_tv = (double *)ar.get((size_t)Vt.nseg * 24);
+            if (ar.rc) return ar.rc;
+            if ((rc = launch_voxel_mean(ctx, ar, false, d_t, Vt.idx, Vt.starts, Vt.nseg, m->n, d_tv, Vt.sorted))) return rc;
+            *d_tv_out = d_tv;
+            *mt_out = Vt.nseg;
+            return R3D_OK;
+        }
+        const int c = m->vt_cur;
+        if ((rc = vt_reserve(m, m->vt_keys[c], Vt.nseg, 8)) || (rc = vt_reserve(m, m->vt_sums[c], Vt.nseg, 24)) || (rc = vt_reserve(m, m->vt_cnt[c], Vt.nseg, 4))) return rc;
+        k_vt_build<8><<<(unsigned)((Vt.nseg + 255) / 256), 256, 0, ctx->stream>>>(Vt.sorted, Vt.starts, Vt.nseg, m->n, bounds[0] - 0.5 * voxel,
+                                                                               bounds[1] - 0.5 * voxel, bounds[2] - 0.5 * voxel, voxel,
+                                                                               (unsigned long long *)m->vt_keys[c].p, (double *)m->vt_sums[c].p, (int *)m->vt_cnt[c].p);
+        R3D_HIP(ctx, hipGetLastError());
+        for (int a = 0; a < 3; a++) { m->vt_min[a] = bounds[a]; m->vt_max[a] = bounds[3 + a]; }
+        m->vt_n = Vt.nseg;
+        m->vt_voxel = voxel;
+        m->vt_valid = true;
+        m->vt_rebuilds++;
+    } else if (ns > 0) {
+        double nmx[3], org[3];
+        for (int a = 0; a < 3; a++) { nmx[a] = std::max(m->vt_max[a], smx[a]); org[a] = m->vt_min[a] - 0.5 * voxel; }
+        if (!key_space_ok(m->vt_min, nmx)) { m->vt_valid = false; return model_target_voxels(m, ar, voxel, d_tv_out, mt_out); }
+        VoxelSegs V;
+        if ((rc = voxel_segments(ctx, ar, d_t + m->vt_pts * 3, ns, voxel, V, false, org, nmx))) return rc;
+        const int c = m->vt_cur, o = c ^ 1;
+        const int64_t cap = m->vt_n + V.nseg;
+        if ((rc = vt_reserve(m, m->vt_keys[o], cap, 8)) || (rc = vt_reserve(m, m->vt_sums[o], cap, 24)) || (rc = vt_reserve(m, m->vt_cnt[o], cap, 4))) return rc;
+        unsigned long long *segkey = (unsigned long long *)ar.get((size_t)V.nseg * 8);
+        int64_t *ins = (int64_t *)ar.get((size_t)V.nseg * 8);
+        double *nsum = (double *)ar.get((size_t)V.nseg * 24);
+        int *is_new = (int *)ar.get((size_t)V.nseg * 4), *rank = (int *)ar.get((size_t)V.nseg * 4), *ncnt = (int *)ar.get((size_t)V.nseg * 4);
+        if (ar.rc) return ar.rc;
+        const unsigned nbs = (unsigned)((V.nseg + 255) / 256);
+        k_vt_update<<<nbs, 256, 0, ctx->stream>>>(V.sorted, V.starts, V.nseg, ns, org[0], org[1], org[2], voxel, (const unsigned long long *)m->vt_keys[c].p,
+                                                  m->vt_n, (double *)m->vt_sums[c].p, (int *)m->vt_cnt[c].p, segkey, is_new, ins, nsum, ncnt);
+        if (int src = dev_exclusive_scan<int>(ctx, ar, is_new, rank, V.nseg)) return src;
+        int last_rank = 0, last_flag = 0;
+        {
+            PinRead rd(ctx);
+            int prc;
+            if ((prc = rd.add(&last_rank, rank + (V.nseg - 1), 4)) || (prc = rd.add(&last_flag, is_new + (V.nseg - 1), 4)) || (prc = rd.wait())) return prc;
+        }
+        const int total_new = last_rank + last_flag;
+        if (total_new > 0) {
+            k_vt_merge<<<(unsigned)((m->vt_n + V.nseg + 255) / 256), 256, 0, ctx->stream>>>(
+                (const unsigned long long *)m->vt_keys[c].p, (const double *)m->vt_sums[c].p, (const int *)m->vt_cnt[c].p, m->vt_n, segkey, is_new, rank, ins, nsum,
+                ncnt, V.nseg, total_new, (unsigned long long *)m->vt_keys[o].p, (double *)m->vt_sums[o].p, (int *)m->vt_cnt[o].p);
+            m->vt_cur = o;
+            m->vt_n += total_new;
+        }
+        R3D_HIP(ctx, hipGetLastError());
+        for (int a = 0; a < 3; a++) m->vt_max[a] = nmx[a];
+        m->vt_updates++;
+    }
+    m->vt_pts = m->n;
+    tkeys = (const unsigned long long *)m->vt_keys[m->vt_cur].p;
+    (void)tkeys;
+    double *d_tv = (double *)ar.get((size_t)m->vt_n * 24);
+    if (ar.rc) return ar.rc;
+    k_vt_means<<<(unsigned)((m->vt_n + 255) / 256), 256, 0, ctx->stream>>>((const double *)m->vt_sums[m->vt_cur].p, (const int *)m->vt_cnt[m->vt_cur].p, m->vt_n, d_tv);
+    R3D_HIP(ctx, hipGetLastError());
+    *d_tv_out = d_tv;
+    *mt_out = m->vt_n;
+    return R3D_OK;
+}
 int model_align_checks(r3d_model *m, const r3d_align_params *p, const char *who) {
     r3d_ctx *ctx = m->ctx;
     if (m->n <= 0) return r3d_fail(ctx, R3D_E_BADARG, "%s: the model is empty (append the first frame)", who);
@@ -3403,14 +3652,9 @@ int model_align_core(r3d_model *m, DevArena &ar, const r3d_align_params *p, doub
         d_s = d_sv;
         d_c = d_cv;
         ms = V.nseg;
-        VoxelSegs Vt;
-        if ((rc = voxel_segments(ctx, ar, d_t, m->n, p->voxel_size, Vt))) return rc;
-        double *d_tv = (double *)ar.get((size_t)Vt.nseg * 24);
-        if (ar.rc) return ar.rc;
-        if ((rc = launch_voxel_mean(ctx, ar, false, d_t, Vt.idx, Vt.starts, Vt.nseg, m->n, d_tv, Vt.sorted))) return rc;
-        R3D_HIP(ctx, hipGetLastError());
+        double *d_tv = nullptr;
+        if ((rc = model_target_voxels(m, ar, p->voxel_size, &d_tv, &mt))) return rc;
         d_t = d_tv;
-        mt = Vt.nseg;
     }
     // pointcloud_alignment.py:27-28 estimates normals on both clouds.  The point-to-point estimator never reads them and the
     // model's operator+= drops the frame's normals unless the model carries normals itself, so they are computed only where

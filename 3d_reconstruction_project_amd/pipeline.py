@@ -95,6 +95,11 @@ def fuse_depth_frames(depth_images, camera, colors=None, verbose=False, ctx=None
     if model is None:
         return PointCloud()
     pts, cols, nrm = model.download()
+    if log is not None:
+        v, r, u = model.voxel_table_stats()
+        log_stats = {"voxel_table": {"voxels": v, "rebuilds": r, "updates": u}}
+        if log:
+            log[-1].update(log_stats)
     model.close()
     return PointCloud(pts, cols, nrm)
 
@@ -209,8 +214,10 @@ def views_to_cloud_tensors(pairs, d_disps, width, height, Q, matcher, outs, clou
             prio = -1 if os.environ.get("R3D_CLOUD_PRIO") == "1" else 0
             sbs = [torch.cuda.Stream(device=dev, priority=prio) for _ in cctxs]
             prev = [c.get_stream() for c in cctxs]
-            for c, sb in zip(cctxs, sbs):
+            for c, sb, pv in zip(cctxs, sbs, prev):
                 sb.wait_stream(sa)
+                if pv:        # work the cloud context queued earlier on its previous stream (it reuses the same arena) stays ahead
+                    sb.wait_stream(torch.cuda.ExternalStream(pv, device=dev))
                 c.set_stream(sb.cuda_stream)
             try:
                 matcher.compute_batch_device([p[0] for p in pairs], [p[1] for p in pairs], width, height, width, list(d_disps),
@@ -232,9 +239,11 @@ def views_to_cloud_tensors(pairs, d_disps, width, height, Q, matcher, outs, clou
                     with ThreadPoolExecutor(len(cctxs)) as pool:
                         for f in [pool.submit(chain, w) for w in range(len(cctxs))]:
                             f.result()                       # re-raises a worker's exception here
+            finally:
+                # on EVERY path (a worker may have raised with the other chains' kernels still queued): the matcher's stream joins
+                # the side streams, so that the ctx.sync() below also covers kernels that write outs[i] / read d_disps[i]
                 for sb in sbs:
                     sa.wait_stream(sb)
-            finally:
                 for c, p in zip(cctxs, prev):
                     c.set_stream(p)
     finally:

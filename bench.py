@@ -62,8 +62,9 @@ def bench_gicp(r3d, ctx, n=1_000_000, iters=20, cpu=True):
     co.registration(src, tgt, 0.02, mode=co.GICP, max_iteration=2, relative_fitness=-1, relative_rmse=-1,
                     source_normals=sn, target_normals=tn, ctx=ctx)                        # warm-up (allocations)
     runs = [co.registration(src, tgt, 0.02, mode=co.GICP, max_iteration=iters, relative_fitness=-1, relative_rmse=-1,
-                            source_normals=sn, target_normals=tn, ctx=ctx) for _ in range(3)]
-    res = sorted(runs, key=lambda r: r["loop_ms"])[1]        # median of 3 repetitions
+                            source_normals=sn, target_normals=tn, ctx=ctx) for _ in range(5)]
+    by_loop = sorted(runs, key=lambda r: r["loop_ms"])
+    res = by_loop[len(by_loop) // 2]                         # median of 5 repetitions; the spread is reported (loop_ms_repeats)
     # the same registration on clouds that are already resident in HBM (r3d_icp_dev): set-up without the four 24 MB uploads
     d_bufs = [ctx.to_device(a) for a in (src, sn, tgt, tn)]
     resident = sorted((co.registration_device(d_bufs[0], len(src), d_bufs[2], len(tgt), 0.02, mode=co.GICP, max_iteration=iters,
@@ -89,6 +90,11 @@ def bench_gicp(r3d, ctx, n=1_000_000, iters=20, cpu=True):
         raise SystemExit(f"GICP bench: ||T - T*||_F = {err:.3e} > 1e-3")
     out = {"metric": "GICP iterations/s @1M pts", "value": round(1e3 / per_iter_ms, 2), "unit": "iterations/s",
            "iterations": res["iterations"], "ms_per_iteration": round(per_iter_ms, 4),
+           # a queue stall on the box (10-60 ms once in a few dozen loops, profiles/r03_stall_device_clock.log) must show in the
+           # record instead of vanishing in a median
+           "loop_ms_repeats": {"n": len(by_loop), "min": round(by_loop[0]["loop_ms"], 3), "median": round(res["loop_ms"], 3),
+                               "max": round(by_loop[-1]["loop_ms"], 3)},
+           "stall_suspect": bool(by_loop[-1]["loop_ms"] > 3.0 * res["loop_ms"]),
            "setup_ms": {"normals_knn20_both_clouds": round(1e3 * normals_s, 1), "normals_knn20_both_clouds_first_call": round(1e3 * normals_cold_s, 1),
                         "grid_sort_upload": round(res["setup_ms"], 1), "grid_sort_resident": round(resident["setup_ms"], 2)},
            "fitness": round(res["fitness"], 5), "inlier_rmse": res["inlier_rmse"], "T_error_frobenius": err,
@@ -550,6 +556,20 @@ def main():
                  "pipeline_frac": round(ALG_BYTES["map"] * nb / pdt / HBM_PEAK, 4),
                  "entry_point": "r3d_sgbm_compute_batch_dev", "n_gpus": world}
 
+    # informational third leg (never `value`; SURVEY.md 8d asks for it beside the device-resident figure): the same maps through the
+    # HOST-buffer entry point r3d_sgbm_compute with pageable numpy arrays: 2 x 8 MB up and 16 MB down per map included
+    host_api = None
+    if lanes == 1 and not args.no_extras and rank == 0:
+        m.compute(L, R)                                         # staging buffers allocate at first use
+        nh = max(4, min(args.steps, 10))
+        th0 = time.perf_counter()
+        for _ in range(nh):
+            m.compute(L, R)
+        hdt = time.perf_counter() - th0
+        host_api = {"value": round(nh / hdt, 2), "unit": "disparity-maps/s", "ms_per_map": round(1e3 * hdt / nh, 4), "maps": nh,
+                    "entry_point": "r3d_sgbm_compute (pageable numpy arrays in and out: H2D 2 x %.1f MB + D2H %.1f MB per map over PCIe, "
+                                   "synchronous)" % (W * H / 1e6, 2 * W * H / 1e6), "n_gpus": 1}
+
     # secondary metric on every rank when N > 1 (weak scaling: one 1M-point cloud pair per GPU, no communication inside the
     # registration loop); rank 0 reports the sum of the per-rank rates
     gicp_multi = None
@@ -629,7 +649,7 @@ def main():
                            "maps_in_flight_per_gpu": lanes},
                 "ms_per_step_repeats": ({"n": len(rep_ms), "min": round(min(rep_ms), 4), "median": round(sorted(rep_ms)[len(rep_ms) // 2], 4),
                                          "max": round(max(rep_ms), 4)} if rep_ms else None),
-                "roofline": roofline, "cpu_baseline": cpu, "pipelined": piped, "frame_loop": frame_loop, "secondary": gicp, "c5": c5}
+                "roofline": roofline, "cpu_baseline": cpu, "pipelined": piped, "host_api": host_api, "frame_loop": frame_loop, "secondary": gicp, "c5": c5}
 
     # single-rank legs that need no collective (rank 0 only): CPU baseline, frame loop, GICP at N = 1
     cpu = frame_loop = None

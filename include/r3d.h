@@ -258,6 +258,11 @@ int r3d_model_create(r3d_ctx *ctx, r3d_model **out);
 void r3d_model_destroy(r3d_model *m);
 int r3d_model_clear(r3d_model *m);
 int r3d_model_size(r3d_model *m, int64_t *n, int32_t *has_colors, int32_t *has_normals);
+/* The model keeps its legacy voxel grid (pointcloud_alignment.py:23 re-down-samples the target every frame, main.py:48) as a resident
+ * table that a new frame is merged into while the model's minimum corner -- the grid's origin -- stays where it is; it is rebuilt
+ * from all points otherwise (same means bit for bit either way).  Diagnostics: voxels in the table, full rebuilds and incremental
+ * updates so far.  Any pointer may be NULL. */
+int r3d_model_voxel_table_stats(r3d_model *m, int64_t *voxels, int32_t *rebuilds, int32_t *updates);
 /* combined.points = frame.points ... (main.py:42-45) and `combined += cloud` for host clouds; colors / normals may be NULL */
 int r3d_model_append(r3d_model *m, const double *xyz, const double *colors, const double *normals, int64_t n);
 /* main.py:48-49: aligned = align_point_clouds(frame, combined, threshold, voxel_size, max_iter); combined += aligned.

@@ -113,6 +113,26 @@ def test_fuse_loop_gicp_flavour_all_eight_c4_frames(r3d):
     assert np.abs(got.points[n0:n0 + n1] - co.transform_points(wlog[0]["T"], frames[1][0])).max() < 1e-8
 
 
+def test_incremental_model_voxel_table_equals_full_revoxelisation(r3d):
+    """SURVEY section 5 "growing target cloud": the resident model keeps its legacy voxel grid as a table that each aligned frame
+    is merged into (full rebuild only when the model's minimum corner moves).  Over 24 frames of the recorded scan the loop must
+    give, bit for bit, what the reference-shaped loop gives that re-voxelises every model point for every frame
+    (pointcloud_alignment.py:22-23) -- and the incremental path must actually have run."""
+    cam = r3d.cloud_ops.depth_camera(INTR)
+    depths = [co.read_png16(os.path.join(GOLDEN, f"output84/depth_{i:05d}.png")) for i in range(8, 32)]
+    log = []
+    a = r3d.pipeline.fuse_depth_frames(depths, cam, log=log)
+    vt = log[-1]["voxel_table"]
+    assert vt["updates"] >= 5 and vt["rebuilds"] >= 1 and vt["updates"] + vt["rebuilds"] == len(log), vt
+    clouds = [r3d.PointCloud(co.backproject(d, INTR)[0]) for d in depths]
+    b = r3d.pipeline.fuse(clouds, flavour="icp", resident=False)              # host model: voxel_down_sample of everything, every frame
+    np.testing.assert_array_equal(a.points, b.points)
+    # the table against the oracle's voxel grid of the final model minus its last frame (what the last alignment was run against)
+    n_last = log[-1]["appended"]
+    want = co.voxel_down_sample(np.asarray(a.points)[:-n_last], 0.01)
+    assert vt["voxels"] == len(want)
+
+
 def test_resident_model_loop_equals_host_model_loop(r3d):
     """The HBM-resident model (r3d_model_*) must give exactly what the reference-shaped loop over host clouds gives (which
     re-uploads and re-voxelises the whole model per frame), for both flavours, colours included."""

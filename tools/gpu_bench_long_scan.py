@@ -38,6 +38,7 @@ out["setup_ms_per_frame"] = [round(r["setup_ms"], 3) for r in log]
 out["loop_ms_per_frame"] = [round(r["loop_ms"], 3) for r in log]
 out["iterations_per_frame"] = [int(r["iterations"]) for r in log]
 out["model_points_per_frame"] = [int(r["model_points"]) for r in log]
+out["voxel_table"] = log[-1].get("voxel_table")
 out["setup_growth_frame9_to_last"] = round(log[-1]["setup_ms"] / log[0]["setup_ms"], 2)
 out["checksum"] = [float(x) for x in np.asarray(model.points).sum(0)]
 print(json.dumps(out))
