@@ -89,6 +89,28 @@ __global__ void __launch_bounds__(256) k_bbox_partial(const double *__restrict__
     if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = sm[threadIdx.x][0];
 }
 
+// the same over a point count that is still on the device (n = *c0 + *c1: the last entries of a compaction's scan and flags):
+// the bounding box is enqueued before the host knows how many points there are, and both come back in ONE read
+__global__ void __launch_bounds__(256) k_bbox_partial_dn(const double *__restrict__ p, const int *__restrict__ c0, const int *__restrict__ c1,
+                                                         double *__restrict__ part) {
+    const int64_t n = (int64_t)*c0 + *c1;
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        for (int a = 0; a < 3; a++) { double v = p[i * 3 + a]; mn[a] = fmin(mn[a], v); mx[a] = fmax(mx[a], v); }
+    __shared__ double sm[6][256];
+    for (int a = 0; a < 3; a++) { sm[a][threadIdx.x] = mn[a]; sm[3 + a][threadIdx.x] = mx[a]; }
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int a = 0; a < 3; a++) {
+                sm[a][threadIdx.x] = fmin(sm[a][threadIdx.x], sm[a][threadIdx.x + s]);
+                sm[3 + a][threadIdx.x] = fmax(sm[3 + a][threadIdx.x], sm[3 + a][threadIdx.x + s]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = sm[threadIdx.x][0];
+}
+
 // second stage: one workgroup folds the per-workgroup boxes into one (6 doubles), so the host reads 48 bytes
 __global__ void __launch_bounds__(256) k_bbox_final(const double *__restrict__ part, int nb, double *__restrict__ out6) {
     __shared__ double sm[6][256];
@@ -393,7 +415,16 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
 }
 template <class KEY>
 __global__ void __launch_bounds__(256) k_cs_rank(const CsRun<KEY> *__restrict__ placed, int nruns, const unsigned long long *__restrict__ start,
-                                                 int *__restrict__ final_base) {
+                                                 int *__restrict__ final_base, const unsigned long long *__restrict__ d_total,
+                                                 const int *__restrict__ d_maxruns, int max_runs_allowed) {
+    // deferred mode (d_total != NULL): the host has NOT read the run count and the fallback test yet -- they travel with the
+    // caller's next read-back -- so the grid covers the upper bound (one run per point), the count comes from device memory, and
+    // a bucket population the quadratic step below must not be asked to rank makes the whole kernel a no-op (the host then
+    // discards this sort and runs the radix sort)
+    if (d_total) {
+        if (*d_maxruns > max_runs_allowed) return;
+        nruns = (int)(*d_total >> 32);
+    }
     const int s = blockIdx.x * 256 + threadIdx.x;   // nruns = high word of the scan total, read by the host together with the fallback test
     if ((s & ~63) >= nruns) return;                  // whole wave beyond the list
     const bool valid = s < nruns;
@@ -425,9 +456,10 @@ __global__ void __launch_bounds__(256) k_cs_rank(const CsRun<KEY> *__restrict__ 
 // every point to its final slot; optionally the gathered coordinates as well (the cell-sorted copy a search grid needs)
 template <class KEY>
 __global__ void __launch_bounds__(256) k_cs_emit(const KEY *__restrict__ keys, const int *__restrict__ gid_of, const int *__restrict__ final_base, int64_t n, KEY *__restrict__ keys_out, int *__restrict__ idx_out,
-                                                 const double *__restrict__ pts, double *__restrict__ sorted) {
+                                                 const double *__restrict__ pts, double *__restrict__ sorted, const int *__restrict__ d_maxruns, int max_runs_allowed) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (d_maxruns && *d_maxruns > max_runs_allowed) return;           // deferred mode: k_cs_rank did not run, final_base holds nothing
     const int g = gid_of[i];                                         // = index of the first point of my run
     const int64_t o = (int64_t)final_base[g] + ((int)i - g);
     keys_out[o] = keys[i];
@@ -1762,6 +1794,17 @@ __global__ void __launch_bounds__(256) k_transform(const double *__restrict__ in
     out[i * 3 + 2] = T.r[6] * x + T.r[7] * y + T.r[8] * z + tz;
 }
 
+// k_transform over a count that is still on the device (see k_bbox_partial_dn); the grid covers the upper bound
+__global__ void __launch_bounds__(256) k_transform_dn(const double *__restrict__ in, const int *__restrict__ c0, const int *__restrict__ c1, Rigid T,
+                                                      double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)*c0 + *c1) return;
+    const double x = in[i * 3], y = in[i * 3 + 1], z = in[i * 3 + 2];
+    out[i * 3] = T.r[0] * x + T.r[1] * y + T.r[2] * z + T.t[0];
+    out[i * 3 + 1] = T.r[3] * x + T.r[4] * y + T.r[5] * z + T.t[1];
+    out[i * 3 + 2] = T.r[6] * x + T.r[7] * y + T.r[8] * z + T.t[2];
+}
+
 // several blocks of triplets, each with its own rigid transform, in ONE launch (the fuse step of the multi-view exchange: eight
 // views x (points, normals) were sixteen launches of ~2 us of work each behind ~18 us of host call overhead each)
 constexpr int TB_MAX = 16;
@@ -2083,6 +2126,31 @@ struct Grid {
     double mn[3], mx[3];
 };
 
+// a point at infinity (e.g. a zero disparity reprojected through Q) or a NaN has no cell: refuse instead of building a grid
+// around it (fmin/fmax drop NaNs, so those show up as an untouched +-1e300 bound only if every value is NaN)
+int bbox_check(r3d_ctx *ctx, const double mn[3], const double mx[3]) {
+    for (int a = 0; a < 3; a++)
+        if (!std::isfinite(mn[a]) || !std::isfinite(mx[a]) || mn[a] > mx[a] || std::fabs(mn[a]) > 1e290 || std::fabs(mx[a]) > 1e290)
+            return r3d_fail(ctx, R3D_E_BADARG, "cloud has non-finite coordinates (axis %d spans [%g, %g])", a, mn[a], mx[a]);
+    return R3D_OK;
+}
+// enqueues the bounding box of the first (*c0 + *c1) points (at most `bound`) and returns where its 6 doubles will be: the caller
+// reads them with its next read-back, together with the count
+int cloud_bbox_enqueue_dn(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t bound, const int *c0, const int *c1, const double **d_box6,
+                          double *d_dst6 = nullptr /* where to leave the box (a buffer that outlives the arena); default: arena */) {
+    const int nb = (int)std::min<int64_t>((bound + 255) / 256, 1024);
+    double *part = (double *)ar.get((size_t)(nb + 1) * 6 * 8);
+    if (ar.rc) return ar.rc;
+    if (c0) k_bbox_partial_dn<<<nb, 256, 0, ctx->stream>>>(d_pts, c0, c1, part);
+    else k_bbox_partial<<<nb, 256, 0, ctx->stream>>>(d_pts, bound, part);       // the count is known: `bound` IS the count
+    double *dst = d_dst6 ? d_dst6 : part + (size_t)nb * 6;
+    k_bbox_final<<<1, 256, 0, ctx->stream>>>(part, nb, dst);
+    R3D_HIP(ctx, hipGetLastError());
+    if (d_box6) *d_box6 = dst;
+    return R3D_OK;
+}
+// an extra item for somebody else's read-back (PinRead): a value the caller wants on the host, produced earlier on the device
+struct PinExtra { void *host = nullptr; const void *dev = nullptr; size_t bytes = 0; };
 int cloud_bbox(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, double mn[3], double mx[3]) {
     const int nb = (int)std::min<int64_t>((n + 255) / 256, 1024);
     double *part = (double *)ar.get((size_t)(nb + 1) * 6 * 8);
@@ -2097,12 +2165,7 @@ int cloud_bbox(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, doubl
         if ((prc = rd.add(h, part + (size_t)nb * 6, sizeof h)) || (prc = rd.wait())) return prc;
     }
     for (int a = 0; a < 3; a++) { mn[a] = h[a]; mx[a] = h[3 + a]; }
-    // a point at infinity (e.g. a zero disparity reprojected through Q) or a NaN has no cell: refuse instead of building a
-    // grid around it (fmin/fmax drop NaNs, so those show up as an untouched +-1e300 bound only if every value is NaN)
-    for (int a = 0; a < 3; a++)
-        if (!std::isfinite(mn[a]) || !std::isfinite(mx[a]) || mn[a] > mx[a] || std::fabs(mn[a]) > 1e290 || std::fabs(mx[a]) > 1e290)
-            return r3d_fail(ctx, R3D_E_BADARG, "cloud has non-finite coordinates (axis %d spans [%g, %g])", a, mn[a], mx[a]);
-    return R3D_OK;
+    return bbox_check(ctx, mn, mx);
 }
 
 // exclusive scan of n ints / packed 64-bit counters on the ctx stream (k_scan_sums + k_scan_apply)
@@ -2140,10 +2203,22 @@ int radix_sort_by_cell_t(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_
 
 constexpr int CS_MAX_RUNS = 4096;          // runs per bucket above which k_cs_rank's quadratic step is declined (radix fallback)
 constexpr int64_t CS_MAX_BUCKETS = 1ll << 26;
+// A sort whose host round trip (run count + fallback test) is DEFERRED: the caller adds d_total / d_maxruns to its own next
+// read-back (PinRead) and calls ok(); if that says no, the sorted arrays are garbage and the caller sorts again with impl = 1.
+struct SortDefer {
+    const unsigned long long *d_total = nullptr;   // runs << 32 | points
+    const int *d_maxruns = nullptr;
+    int64_t n = 0;
+    bool used = false;                             // false: the sort that ran was complete on its own (radix path)
+    unsigned long long h_total = 0;
+    int h_maxruns = 0;
+    int add_to(PinRead &rd) { if (!used) return R3D_OK; if (int rc = rd.add(&h_total, d_total, 8)) return rc; return rd.add(&h_maxruns, d_maxruns, 4); }
+    bool ok() const { return !used || (h_maxruns <= CS_MAX_RUNS && (int64_t)(unsigned)h_total == n); }
+};
 // returns R3D_OK with *done = false when it declines (more than CS_MAX_RUNS runs in one bucket)
 template <class KEY>
 int counting_sort_by_cell_t(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, const CsGeom &g, int64_t nbuckets, void **keys_sorted,
-                            int **idx_sorted, double *sorted_pts, bool *done) {
+                            int **idx_sorted, double *sorted_pts, bool *done, SortDefer *defer = nullptr) {
     *done = false;
     KEY *keys = (KEY *)ar.get((size_t)n * sizeof(KEY)), *keys_out = (KEY *)ar.get((size_t)n * sizeof(KEY));
     int *gid_of = (int *)ar.get((size_t)n * 4), *idx_out = (int *)ar.get((size_t)n * 4), *final_base = (int *)ar.get((size_t)n * 4);
@@ -2157,6 +2232,20 @@ int counting_sort_by_cell_t(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int
     k_cs_runs<KEY><<<nb, 256, 0, ctx->stream>>>(d_pts, n, g, keys, gid_of, cnt, runs);
     int rc = dev_exclusive_scan<unsigned long long>(ctx, ar, cnt, start, nbuckets + 1, nullptr, ctr);
     if (rc) return rc;
+    if (defer) {   // no round trip here: launch over the upper bounds, counts and the fallback test stay on the device for now
+        k_cs_place<KEY><<<nb, 256, 0, ctx->stream>>>(runs, gid_of, n, start, placed);
+        k_cs_rank<KEY><<<nb, 256, 0, ctx->stream>>>(placed, 0, start, final_base, start + nbuckets, ctr, CS_MAX_RUNS);
+        k_cs_emit<KEY><<<nb, 256, 0, ctx->stream>>>(keys, gid_of, final_base, n, keys_out, idx_out, d_pts, sorted_pts, ctr, CS_MAX_RUNS);
+        R3D_HIP(ctx, hipGetLastError());
+        defer->d_total = start + nbuckets;
+        defer->d_maxruns = ctr;
+        defer->n = n;
+        defer->used = true;
+        *keys_sorted = keys_out;
+        *idx_sorted = idx_out;
+        *done = true;
+        return R3D_OK;
+    }
     // ONE host round trip: the scan total (runs << 32 | points: cnt[nbuckets] is 0, so start[nbuckets] is the total) and the
     // largest run count of a bucket, which decides whether the quadratic ranking step is affordable
     struct { unsigned long long total; int max_runs; } h = {0, 0};
@@ -2172,8 +2261,8 @@ int counting_sort_by_cell_t(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int
     if (h.max_runs > CS_MAX_RUNS) return R3D_OK;
     const int nruns = (int)(h.total >> 32), nrb = (nruns + 255) / 256;
     k_cs_place<KEY><<<nb, 256, 0, ctx->stream>>>(runs, gid_of, n, start, placed);
-    k_cs_rank<KEY><<<nrb, 256, 0, ctx->stream>>>(placed, nruns, start, final_base);
-    k_cs_emit<KEY><<<nb, 256, 0, ctx->stream>>>(keys, gid_of, final_base, n, keys_out, idx_out, d_pts, sorted_pts);
+    k_cs_rank<KEY><<<nrb, 256, 0, ctx->stream>>>(placed, nruns, start, final_base, nullptr, nullptr, 0);
+    k_cs_emit<KEY><<<nb, 256, 0, ctx->stream>>>(keys, gid_of, final_base, n, keys_out, idx_out, d_pts, sorted_pts, nullptr, 0);
     R3D_HIP(ctx, hipGetLastError());
     *keys_sorted = keys_out;
     *idx_sorted = idx_out;
@@ -2185,7 +2274,9 @@ int counting_sort_by_cell_t(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int
 // order.  The keys are 32-bit whenever the key space allows; *keys32 tells the caller which type keys_sorted points to.
 // Default: the run-based counting sort above; the library radix sort when that declines.
 int sort_by_cell(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, const double org[3], double cell, const int dims[3],
-                 int key_order, void **keys_sorted, bool *keys32, int **idx_sorted, double *sorted_pts = nullptr, int impl = -1) {
+                 int key_order, void **keys_sorted, bool *keys32, int **idx_sorted, double *sorted_pts = nullptr, int impl = -1,
+                 SortDefer *defer = nullptr) {
+    if (defer) *defer = SortDefer();
     int bits = 1;
     if (key_order == 2) {
         int m = std::max(dims[0], std::max(dims[1], dims[2])), b1 = 1;
@@ -2221,8 +2312,8 @@ int sort_by_cell(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, con
     }
     if (!force_radix && nbuckets <= CS_MAX_BUCKETS && n < 0x7fffffff) {
         bool done = false;
-        const int rc = *keys32 ? counting_sort_by_cell_t<unsigned>(ctx, ar, d_pts, n, g, nbuckets, keys_sorted, idx_sorted, sorted_pts, &done)
-                               : counting_sort_by_cell_t<unsigned long long>(ctx, ar, d_pts, n, g, nbuckets, keys_sorted, idx_sorted, sorted_pts, &done);
+        const int rc = *keys32 ? counting_sort_by_cell_t<unsigned>(ctx, ar, d_pts, n, g, nbuckets, keys_sorted, idx_sorted, sorted_pts, &done, defer)
+                               : counting_sort_by_cell_t<unsigned long long>(ctx, ar, d_pts, n, g, nbuckets, keys_sorted, idx_sorted, sorted_pts, &done, defer);
         if (rc || done) return rc;
     }
     const int rc = *keys32 ? radix_sort_by_cell_t<unsigned>(ctx, ar, d_pts, n, org, cell, dims, key_order, bits, keys_sorted, idx_sorted)
@@ -2237,11 +2328,22 @@ int sort_by_cell(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, con
 
 // Builds the search grid.  cell_hint: minimum useful cell (search radius, or <= 0 for pure kNN); the cell is
 // refined so that occupied cells hold about `target_occ` points, and coarsened to keep the dense table <= 2^26 cells.
-int grid_build(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, double cell_hint, double target_occ, Grid &G, bool dense_table = false) {
+// enclosing[6] (optional): a box known to contain every point (e.g. the bounding box of the cloud these points are voxel means
+// of): used, slightly widened, instead of a bounding-box pass and its host round trip.  A search grid's origin and extent decide
+// only which cell a point is filed under; what the searches return does not depend on them.
+int grid_build(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, double cell_hint, double target_occ, Grid &G, bool dense_table = false,
+               const double *enclosing = nullptr) {
     if (n <= 0) return r3d_fail(ctx, R3D_E_BADARG, "grid: empty cloud");
     if (n > 0x7fffffff) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "grid: more than 2^31-1 points");
-    int rc = cloud_bbox(ctx, ar, d_pts, n, G.mn, G.mx);
-    if (rc) return rc;
+    int rc;
+    if (enclosing) {
+        for (int a = 0; a < 3; a++) {   // a mean of values inside [lo, hi] can leave it by a rounding: widen by far more than that
+            const double pad = 1e-9 * std::max(std::max(std::fabs(enclosing[a]), std::fabs(enclosing[3 + a])), enclosing[3 + a] - enclosing[a]) + 1e-300;
+            G.mn[a] = enclosing[a] - pad;
+            G.mx[a] = enclosing[3 + a] + pad;
+        }
+        if ((rc = bbox_check(ctx, G.mn, G.mx))) return rc;
+    } else if ((rc = cloud_bbox(ctx, ar, d_pts, n, G.mn, G.mx))) return rc;
     double ext[3];
     for (int a = 0; a < 3; a++) ext[a] = std::max(G.mx[a] - G.mn[a], 1e-9);
     // surface-like data: occupied cells ~ (extent/cell)^2 * const.  Start from the volume / area heuristic and clamp.
@@ -2558,8 +2660,10 @@ int upload(r3d_ctx *ctx, DevArena &ar, const double *h, int64_t n3, double **d) 
 // ---- device-pointer cores shared by the host-buffer entry points and the fused device-resident chain -------------
 
 // disparity (device) -> compacted xyz (device).  max_depth > 0 additionally drops points with |z| > max_depth.
+// pose4x4 (optional) moves the points; bounds_out[6] (optional) receives their bounding box -- enqueued BEFORE the host knows the
+// point count (kernels over the upper bound w * h with the count read on the device), so count and box are ONE read-back.
 int reproject_core(r3d_ctx *ctx, DevArena &ar, const int16_t *d_d, int w, int h, const double *Q4x4, int min_valid_x16, double max_depth,
-                   bool want_pix, double **d_xyz_out, int **d_pix_out, int64_t *m_out) {
+                   bool want_pix, double **d_xyz_out, int **d_pix_out, int64_t *m_out, const double *pose4x4 = nullptr, double *bounds_out = nullptr) {
     const int64_t n = (int64_t)w * h;
     if (n > 0x7fffffff) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "reproject_disparity: image too large");
     int *flags = (int *)ar.get((size_t)n * 4), *scan = (int *)ar.get((size_t)n * 4);
@@ -2571,6 +2675,31 @@ int reproject_core(r3d_ctx *ctx, DevArena &ar, const int16_t *d_d, int w, int h,
     else k_disp_flags<<<nb, 256, 0, ctx->stream>>>(d_d, n, min_valid_x16, flags);
     if (int src = dev_exclusive_scan<int>(ctx, ar, flags, scan, n)) return src;
     int ls = 0, lf = 0;
+    if (bounds_out) {
+        // arrays sized for the upper bound (every pixel valid); reprojection, pose and bounding box enqueued without a host read
+        double *d_xyz = (double *)ar.get((size_t)n * 24);
+        int *d_pix = want_pix ? (int *)ar.get((size_t)n * 4) : nullptr;
+        if (ar.rc) return ar.rc;
+        k_reproject<<<nb, 256, 0, ctx->stream>>>(d_d, flags, scan, w, n, Q, d_xyz, d_pix);
+        if (pose4x4) {
+            double *d_t = (double *)ar.get((size_t)n * 24);
+            if (ar.rc) return ar.rc;
+            k_transform_dn<<<nb, 256, 0, ctx->stream>>>(d_xyz, scan + (n - 1), flags + (n - 1), to_rigid(pose4x4), d_t);
+            d_xyz = d_t;
+        }
+        const double *d_box = nullptr;
+        if (int brc = cloud_bbox_enqueue_dn(ctx, ar, d_xyz, n, scan + (n - 1), flags + (n - 1), &d_box)) return brc;
+        {
+            PinRead rd(ctx);
+            int prc;
+            if ((prc = rd.add(&ls, scan + (n - 1), 4)) || (prc = rd.add(&lf, flags + (n - 1), 4)) || (prc = rd.add(bounds_out, d_box, 48)) || (prc = rd.wait())) return prc;
+        }
+        const int64_t m = (int64_t)ls + lf;
+        *m_out = m;
+        *d_xyz_out = m ? d_xyz : nullptr;
+        if (d_pix_out) *d_pix_out = m ? d_pix : nullptr;
+        return m ? bbox_check(ctx, bounds_out, bounds_out + 3) : R3D_OK;
+    }
     {
         PinRead rd(ctx);
         int prc;
@@ -2593,7 +2722,9 @@ int reproject_core(r3d_ctx *ctx, DevArena &ar, const int16_t *d_d, int w, int h,
 
 // depth image (host) -> compacted xyz / colours (device); everything below r3d_backproject_depth's argument checks
 int backproject_core(r3d_ctx *ctx, DevArena &ar, const uint16_t *depth, int w, int h, int stride, const r3d_depth_camera *cam,
-                     const uint8_t *color, int cstride, bool want_pix, double **d_xyz_out, double **d_rgb_out, int **d_pix_out, int64_t *m_out) {
+                     const uint8_t *color, int cstride, bool want_pix, double **d_xyz_out, double **d_rgb_out, int **d_pix_out, int64_t *m_out,
+                     double *bounds_out = nullptr /* [6]: the cloud's bounding box, read back together with the count */,
+                     const PinExtra *extra = nullptr /* rides along in that read-back */) {
     const int64_t n = (int64_t)w * h;
     if (n > 0x7fffffff) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "backproject_depth: image too large");
     unsigned short *d_d = (unsigned short *)ar.get((size_t)stride * h * 2);
@@ -2608,6 +2739,26 @@ int backproject_core(r3d_ctx *ctx, DevArena &ar, const uint16_t *depth, int w, i
     k_depth_flags<<<nb, 256, 0, ctx->stream>>>(d_d, w, stride, n, c, flags);
     if (int src = dev_exclusive_scan<int>(ctx, ar, flags, scan, n)) return src;
     int ls = 0, lf = 0;
+    if (bounds_out) {   // as reproject_core: arrays for the upper bound, back-projection and bounding box enqueued, ONE read-back
+        double *d_xyz = (double *)ar.get((size_t)n * 24), *d_rgb = color ? (double *)ar.get((size_t)n * 24) : nullptr;
+        int *d_pix = want_pix ? (int *)ar.get((size_t)n * 4) : nullptr;
+        if (ar.rc) return ar.rc;
+        k_backproject<<<nb, 256, 0, ctx->stream>>>(d_d, d_c, flags, scan, w, stride, cstride, n, c, d_xyz, d_rgb, d_pix);
+        const double *d_box = nullptr;
+        if (int brc = cloud_bbox_enqueue_dn(ctx, ar, d_xyz, n, scan + (n - 1), flags + (n - 1), &d_box)) return brc;
+        {
+            PinRead rd(ctx);
+            int prc;
+            if ((prc = rd.add(&ls, scan + (n - 1), 4)) || (prc = rd.add(&lf, flags + (n - 1), 4)) || (prc = rd.add(bounds_out, d_box, 48)) ||
+                (extra && extra->host && (prc = rd.add(extra->host, extra->dev, extra->bytes))) || (prc = rd.wait())) return prc;
+        }
+        const int64_t m = (int64_t)ls + lf;
+        *m_out = m;
+        *d_xyz_out = m ? d_xyz : nullptr;
+        if (d_rgb_out) *d_rgb_out = m ? d_rgb : nullptr;
+        if (d_pix_out) *d_pix_out = m ? d_pix : nullptr;
+        return m ? bbox_check(ctx, bounds_out, bounds_out + 3) : R3D_OK;
+    }
     {
         PinRead rd(ctx);
         int prc;
@@ -2646,12 +2797,17 @@ struct VoxelSegs {
 // fixed_org / fixed_max (legacy grid only): use this origin and size the key space for points up to fixed_max instead of deriving
 // both from the cloud's own bounding box (the incremental model table: a slice of the model keyed in the MODEL's grid; no
 // bounding-box pass).  bounds_out[6] receives min / max of the cloud when its box was computed here.
+// known_bounds[6] (min, max of exactly these points, already on the host): no bounding-box pass, same grid.
 int voxel_segments(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, double voxel, VoxelSegs &V, bool tensor_grid = false,
-                   const double *fixed_org = nullptr, const double *fixed_max = nullptr, double *bounds_out = nullptr) {
+                   const double *fixed_org = nullptr, const double *fixed_max = nullptr, double *bounds_out = nullptr,
+                   const double *known_bounds = nullptr) {
     double mn[3], mx[3];
     int rc;
     if (fixed_org) {
         for (int a = 0; a < 3; a++) { mn[a] = fixed_org[a] + 0.5 * voxel; mx[a] = fixed_max[a]; }
+    } else if (known_bounds) {
+        for (int a = 0; a < 3; a++) { mn[a] = known_bounds[a]; mx[a] = known_bounds[3 + a]; }
+        if (bounds_out) for (int a = 0; a < 6; a++) bounds_out[a] = known_bounds[a];
     } else {
         if ((rc = cloud_bbox(ctx, ar, d_p, n, mn, mx))) return rc;
         if (bounds_out) for (int a = 0; a < 3; a++) { bounds_out[a] = mn[a]; bounds_out[3 + a] = mx[a]; }
@@ -2677,33 +2833,42 @@ int voxel_segments(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, dou
     // key_order 1: exact legacy index floor((p - origin) / voxel), z fastest => output in lexicographic (kx,ky,kz) order
     V.sorted = (double *)ar.get((size_t)n * 24);
     if (ar.rc) return ar.rc;
-    if ((rc = sort_by_cell(ctx, ar, d_p, n, org, voxel, dims, tensor_grid ? 3 : 1, &keys, &keys32, &V.idx, V.sorted))) return rc;
+    // The sort's own round trip (run count + fallback test) is deferred and travels with the segment count: ONE read-back for the
+    // whole voxel grid.  If the test then says the counting sort had to decline (rare: thousands of runs in one bucket), the
+    // arrays are garbage: sort again with the library radix sort and repeat the segmentation.
     int *flags = (int *)ar.get((size_t)n * 4), *scan = (int *)ar.get((size_t)n * 4);
     V.starts = (int *)ar.get((size_t)n * 4);
     if (ar.rc) return ar.rc;
     const int nb = (int)((n + 255) / 256);
-    if (keys32) k_seg_flags<unsigned><<<nb, 256, 0, ctx->stream>>>((const unsigned *)keys, n, flags);
-    else k_seg_flags<unsigned long long><<<nb, 256, 0, ctx->stream>>>((const unsigned long long *)keys, n, flags);
-    if (int src = dev_exclusive_scan<int>(ctx, ar, flags, scan, n)) return src;
-    k_seg_starts<<<nb, 256, 0, ctx->stream>>>(flags, scan, n, V.starts);
-    int last_scan = 0, last_flag = 0;
-    {
-        PinRead rd(ctx);
-        int prc;
-        if ((prc = rd.add(&last_scan, scan + (n - 1), 4)) || (prc = rd.add(&last_flag, flags + (n - 1), 4)) || (prc = rd.wait())) return prc;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        SortDefer df;
+        if ((rc = sort_by_cell(ctx, ar, d_p, n, org, voxel, dims, tensor_grid ? 3 : 1, &keys, &keys32, &V.idx, V.sorted, attempt ? 1 : -1,
+                               attempt ? nullptr : &df))) return rc;
+        if (keys32) k_seg_flags<unsigned><<<nb, 256, 0, ctx->stream>>>((const unsigned *)keys, n, flags);
+        else k_seg_flags<unsigned long long><<<nb, 256, 0, ctx->stream>>>((const unsigned long long *)keys, n, flags);
+        if (int src = dev_exclusive_scan<int>(ctx, ar, flags, scan, n)) return src;
+        k_seg_starts<<<nb, 256, 0, ctx->stream>>>(flags, scan, n, V.starts);
+        int last_scan = 0, last_flag = 0;
+        {
+            PinRead rd(ctx);
+            int prc;
+            if ((prc = rd.add(&last_scan, scan + (n - 1), 4)) || (prc = rd.add(&last_flag, flags + (n - 1), 4)) || (prc = df.add_to(rd)) || (prc = rd.wait())) return prc;
+        }
+        V.nseg = (int64_t)last_scan + last_flag;
+        if (df.ok()) return R3D_OK;
     }
-    V.nseg = (int64_t)last_scan + last_flag;
-    return R3D_OK;
+    return r3d_fail(ctx, R3D_E_HIP, "voxel grid: the fallback sort did not complete");
 }
 
 // normals of a device cloud into a fresh device buffer
-int normals_core(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, double radius, int max_nn, const double *d_prev, double **d_n_out) {
+int normals_core(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, double radius, int max_nn, const double *d_prev, double **d_n_out,
+                 const double *enclosing = nullptr) {
     Grid G;
     const int k = (int)std::min<int64_t>(max_nn, n);
     int rc;
     double occ = std::max(2.0, k / 5.0);
     if (const char *oe = getenv("R3D_KNN_OCC")) { const double v = atof(oe); if (v >= 0.5 && v <= 256) occ = v; }
-    if ((rc = grid_build(ctx, ar, d_p, n, radius, occ, G))) return rc;
+    if ((rc = grid_build(ctx, ar, d_p, n, radius, occ, G, false, enclosing))) return rc;
     double *d_n = (double *)ar.get((size_t)n * 24);
     if (ar.rc) return ar.rc;
     const size_t lds = (size_t)k * KNN_BLOCK * 12;
@@ -2718,12 +2883,12 @@ int normals_core(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, doubl
 // allows it); everything below r3d_icp's argument checks and uploads
 static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double *d_s, int64_t ns, double *d_sn, double *d_t, int64_t nt,
                     double *d_tn, const double *init4x4, double *T4x4, r3d_icp_stats *stats,
-                    std::chrono::steady_clock::time_point t_begin) {
+                    std::chrono::steady_clock::time_point t_begin, const double *tgt_enclosing = nullptr /* grid_build's `enclosing` */) {
     int rc;
     Grid G;
     double occ = 3.0;   // points per occupied cell the search grid aims at (R3D_ICP_OCC: A/B)
     if (const char *oe = getenv("R3D_ICP_OCC")) { const double v = atof(oe); if (v >= 0.5 && v <= 64) occ = v; }
-    if ((rc = grid_build(ctx, ar, d_t, nt, p->max_correspondence_distance, occ, G, true))) return rc;   // dense table: one load per row in the loop
+    if ((rc = grid_build(ctx, ar, d_t, nt, p->max_correspondence_distance, occ, G, true, tgt_enclosing))) return rc;   // dense table: one load per row in the loop
     // float32 copy for the two-stage search (R3D_ICP_IMPL=exact: all-float64 search, for A/B).  fe = 2 x bound on
     // |float distance - exact distance|: both end points are rounded to float (relative 2^-24 per coordinate), times a
     // safety factor of 2; skipped (exact search) when the coordinates are so large that the margin stops filtering.
@@ -3064,19 +3229,17 @@ static int disparity_to_cloud_impl(r3d_ctx *ctx, const int16_t *d_disp, int32_t 
     int64_t m;
     int rc;
     // depth filter off: still drop points at infinity (W = 0, e.g. disparity 0), which no voxel grid can hold
-    if ((rc = reproject_core(ctx, ar, d_disp, w, h, Q4x4, min_valid_x16, max_depth > 0 ? max_depth : 1.0e300, false, &d_p, nullptr, &m))) return rc;
+    // Host round trips of the chain (each ~25 us of idle GPU): (1) valid-pixel count + bounding box of the posed points, (2) the voxel
+    // grid's segment count + its sort's fallback test, (3) the normal grid's sort -- three, was six: reprojection, pose and box are
+    // enqueued over the upper bound w * h before the count is known; the voxel sort's test travels with the segment count; the
+    // normal grid reuses the box (voxel means lie inside it)
+    double box[6];
+    if ((rc = reproject_core(ctx, ar, d_disp, w, h, Q4x4, min_valid_x16, max_depth > 0 ? max_depth : 1.0e300, false, &d_p, nullptr, &m, pose4x4, box))) return rc;
     *out_n = 0;
     if (m == 0) return R3D_OK;
-    if (pose4x4) {
-        double *d_t = (double *)ar.get((size_t)m * 24);
-        if (ar.rc) return ar.rc;
-        k_transform<<<(unsigned)((m + 255) / 256), 256, 0, ctx->stream>>>(d_p, m, to_rigid(pose4x4), 0, d_t);
-        R3D_HIP(ctx, hipGetLastError());
-        d_p = d_t;
-    }
     if (voxel > 0) {
         VoxelSegs V;
-        if ((rc = voxel_segments(ctx, ar, d_p, m, voxel, V))) return rc;
+        if ((rc = voxel_segments(ctx, ar, d_p, m, voxel, V, false, nullptr, nullptr, nullptr, box))) return rc;
         double *d_v = (double *)ar.get((size_t)V.nseg * 24);
         if (ar.rc) return ar.rc;
         if ((rc = launch_voxel_mean(ctx, ar, false, d_p, V.idx, V.starts, V.nseg, m, d_v, V.sorted))) return rc;
@@ -3087,7 +3250,7 @@ static int disparity_to_cloud_impl(r3d_ctx *ctx, const int16_t *d_disp, int32_t 
     *out_n = m;
     if (m > capacity) return r3d_fail(ctx, R3D_E_BADARG, "disparity_to_cloud: %lld points, output arrays hold %lld", (long long)m, (long long)capacity);
     double *d_n = nullptr;
-    if (max_nn > 0 && (rc = normals_core(ctx, ar, d_p, m, normal_radius, max_nn, nullptr, &d_n))) return rc;
+    if (max_nn > 0 && (rc = normals_core(ctx, ar, d_p, m, normal_radius, max_nn, nullptr, &d_n, box))) return rc;
     const hipMemcpyKind kind = device_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     R3D_HIP(ctx, hipMemcpyAsync(out_xyz, d_p, (size_t)m * 24, kind, ctx->stream));
     if (d_n) R3D_HIP(ctx, hipMemcpyAsync(out_normals, d_n, (size_t)m * 24, kind, ctx->stream));
@@ -3135,6 +3298,8 @@ int r3d_align_point_clouds(r3d_ctx *ctx, const r3d_align_params *p, const double
     if ((rc = upload(ctx, ar, tgt, nt * 3, &d_t))) return rc;
     if (src_colors && (rc = upload(ctx, ar, src_colors, ns * 3, &d_c))) return rc;
     int64_t ms = ns, mt = nt;
+    double tbox[6];
+    const double *tgt_box = nullptr;
     if (p->voxel_size > 0) {  // pointcloud_alignment.py:22-23
         VoxelSegs V;
         if ((rc = voxel_segments(ctx, ar, d_s, ns, p->voxel_size, V))) return rc;
@@ -3147,7 +3312,8 @@ int r3d_align_point_clouds(r3d_ctx *ctx, const r3d_align_params *p, const double
         d_c = d_cv;
         ms = V.nseg;
         VoxelSegs Vt;
-        if ((rc = voxel_segments(ctx, ar, d_t, nt, p->voxel_size, Vt))) return rc;
+        if ((rc = voxel_segments(ctx, ar, d_t, nt, p->voxel_size, Vt, false, nullptr, nullptr, tbox))) return rc;
+        tgt_box = tbox;   // the search grid of the down-sampled target is laid out in the box of the target's own points (as the resident model does)
         double *d_tv = (double *)ar.get((size_t)Vt.nseg * 24);
         if (ar.rc) return ar.rc;
         if ((rc = launch_voxel_mean(ctx, ar, false, d_t, Vt.idx, Vt.starts, Vt.nseg, nt, d_tv, Vt.sorted))) return rc;
@@ -3161,7 +3327,7 @@ int r3d_align_point_clouds(r3d_ctx *ctx, const r3d_align_params *p, const double
         if ((rc = normals_core(ctx, ar, d_t, mt, p->normal_radius, p->normal_max_nn, nullptr, &d_tn))) return rc;
     }
     double T[16];
-    if ((rc = icp_core(ctx, ar, ip, d_s, ms, d_sn, d_t, mt, d_tn, init4x4, T, stats, t_begin))) return rc;  // :35-39
+    if ((rc = icp_core(ctx, ar, ip, d_s, ms, d_sn, d_t, mt, d_tn, init4x4, T, stats, t_begin, tgt_box))) return rc;  // :35-39
     memcpy(T4x4, T, sizeof T);
     double *d_o = (double *)ar.get((size_t)ms * 24), *d_on = d_sn ? (double *)ar.get((size_t)ms * 24) : nullptr;
     if (ar.rc) return ar.rc;
@@ -3412,6 +3578,12 @@ struct r3d_model {
     r3d_buf vt_keys[2], vt_sums[2], vt_cnt[2];
     int vt_cur = 0;
     int vt_rebuilds = 0, vt_updates = 0;   // statistics (r3d_model_voxel_table_stats)
+    // bounding box of the rows [pend_lo, pend_hi) the last alignment appended: computed on the device when they were appended,
+    // fetched with the NEXT call's first read-back (no round trip of its own); pend_host_ok: pend_box holds it already
+    double *d_pend = nullptr;
+    int64_t pend_lo = 0, pend_hi = 0;
+    bool pend_host_ok = false;
+    double pend_box[6] = {0, 0, 0, 0, 0, 0};
 };
 namespace {
 // grows a model buffer to hold `rows` triplets, keeping the first `keep` rows
@@ -3471,6 +3643,7 @@ void r3d_model_destroy(r3d_model *m) {
     (void)hipStreamSynchronize(m->ctx->stream);
     for (r3d_buf *b : {&m->pts, &m->cols, &m->nrms, &m->vt_keys[0], &m->vt_keys[1], &m->vt_sums[0], &m->vt_sums[1], &m->vt_cnt[0], &m->vt_cnt[1]})
         if (b->p) (void)hipFree(b->p);
+    if (m->d_pend) (void)hipFree(m->d_pend);
     delete m;
 }
 
@@ -3480,6 +3653,8 @@ int r3d_model_clear(r3d_model *m) {
     m->has_colors = m->has_normals = false;
     m->vt_valid = false;
     m->vt_n = m->vt_pts = 0;
+    m->pend_lo = m->pend_hi = 0;
+    m->pend_host_ok = false;
     return R3D_OK;
 }
 
@@ -3525,14 +3700,14 @@ int vt_reserve(r3d_model *m, r3d_buf &b, int64_t rows, size_t elem) {
 // pointcloud_alignment.py:23 for the resident model: the legacy voxel grid of ALL model points, as means in lexicographic voxel
 // order in a fresh arena buffer.  Default: the incremental table above (full rebuild whenever the model's minimum corner moved, the
 // voxel size changed or the table does not exist); R3D_MODEL_IMPL=rebuild: the full sort of every model point, every frame.
-int model_target_voxels(r3d_model *m, DevArena &ar, double voxel, double **d_tv_out, int64_t *mt_out) {
+int model_target_voxels(r3d_model *m, DevArena &ar, double voxel, double **d_tv_out, int64_t *mt_out, double *box_out /* [6]: the model's box */) {
     r3d_ctx *ctx = m->ctx;
     int rc;
     double *d_t = (double *)m->pts.p;
     static const bool always_rebuild = [] { const char *e = getenv("R3D_MODEL_IMPL"); return e && !strcmp(e, "rebuild"); }();
     if (always_rebuild) {
         VoxelSegs Vt;
-        if ((rc = voxel_segments(ctx, ar, d_t, m->n, voxel, Vt))) return rc;
+        if ((rc = voxel_segments(ctx, ar, d_t, m->n, voxel, Vt, false, nullptr, nullptr, box_out))) return rc;
         double *d_tv = (double *)ar.get((size_t)Vt.nseg * 24);
         if (ar.rc) return ar.rc;
         if ((rc = launch_voxel_mean(ctx, ar, false, d_t, Vt.idx, Vt.starts, Vt.nseg, m->n, d_tv, Vt.sorted))) return rc;
@@ -3544,7 +3719,10 @@ int model_target_voxels(r3d_model *m, DevArena &ar, double voxel, double **d_tv_
     const int64_t ns = m->n - m->vt_pts;
     double smn[3], smx[3];
     if (!rebuild && ns > 0) {
-        if ((rc = cloud_bbox(ctx, ar, d_t + m->vt_pts * 3, ns, smn, smx))) return rc;
+        if (m->pend_host_ok && m->pend_lo == m->vt_pts && m->pend_hi == m->n) {   // the slice is the block the last alignment appended
+            for (int a = 0; a < 3; a++) { smn[a] = m->pend_box[a]; smx[a] = m->pend_box[3 + a]; }
+            if ((rc = bbox_check(ctx, smn, smx))) return rc;
+        } else if ((rc = cloud_bbox(ctx, ar, d_t + m->vt_pts * 3, ns, smn, smx))) return rc;
         for (int a = 0; a < 3; a++) if (smn[a] < m->vt_min[a]) rebuild = true;   // the grid origin moves: every key changes
     }
     auto key_space_ok = [&](const double *mn, const double *mx) {
@@ -3556,6 +3734,7 @@ int model_target_voxels(r3d_model *m, DevArena &ar, double voxel, double **d_tv_
         VoxelSegs Vt;
         double bounds[6];
         if ((rc = voxel_segments(ctx, ar, d_t, m->n, voxel, Vt, false, nullptr, nullptr, bounds))) return rc;
+        for (int a = 0; a < 6; a++) box_out[a] = bounds[a];
         if (!key_space_ok(bounds, bounds + 3)) {          // more than 2^21 voxels along an axis: no table, the plain full pass
             m->vt_valid = false;
             double *d_tv = (double *)ar.get((size_t)Vt.nseg * 24);
@@ -3579,7 +3758,7 @@ int model_target_voxels(r3d_model *m, DevArena &ar, double voxel, double **d_tv_
     } else if (ns > 0) {
         double nmx[3], org[3];
         for (int a = 0; a < 3; a++) { nmx[a] = std::max(m->vt_max[a], smx[a]); org[a] = m->vt_min[a] - 0.5 * voxel; }
-        if (!key_space_ok(m->vt_min, nmx)) { m->vt_valid = false; return model_target_voxels(m, ar, voxel, d_tv_out, mt_out); }
+        if (!key_space_ok(m->vt_min, nmx)) { m->vt_valid = false; return model_target_voxels(m, ar, voxel, d_tv_out, mt_out, box_out); }
         VoxelSegs V;
         if ((rc = voxel_segments(ctx, ar, d_t + m->vt_pts * 3, ns, voxel, V, false, org, nmx))) return rc;
         const int c = m->vt_cur, o = c ^ 1;
@@ -3619,6 +3798,7 @@ int model_target_voxels(r3d_model *m, DevArena &ar, double voxel, double **d_tv_
     if (ar.rc) return ar.rc;
     k_vt_means<<<(unsigned)((m->vt_n + 255) / 256), 256, 0, ctx->stream>>>((const double *)m->vt_sums[m->vt_cur].p, (const int *)m->vt_cnt[m->vt_cur].p, m->vt_n, d_tv);
     R3D_HIP(ctx, hipGetLastError());
+    for (int a = 0; a < 3; a++) { box_out[a] = m->vt_min[a]; box_out[3 + a] = m->vt_max[a]; }
     *d_tv_out = d_tv;
     *mt_out = m->vt_n;
     return R3D_OK;
@@ -3635,15 +3815,18 @@ int model_align_checks(r3d_model *m, const r3d_align_params *p, const char *who)
 }
 // the frame (d_s, optional colours d_c, ns points) is already on the device in arena `ar`
 int model_align_core(r3d_model *m, DevArena &ar, const r3d_align_params *p, double *d_s, double *d_c, int64_t ns, double *T4x4,
-                     r3d_icp_stats *stats, int64_t *appended, std::chrono::steady_clock::time_point t_begin) {
+                     r3d_icp_stats *stats, int64_t *appended, std::chrono::steady_clock::time_point t_begin,
+                     const double *frame_box = nullptr /* bounding box of the frame's points when the caller already has it */) {
     r3d_ctx *ctx = m->ctx;
     const r3d_icp_params *ip = &p->icp;
     int rc;
     double *d_t = (double *)m->pts.p;
     int64_t ms = ns, mt = m->n;
+    const double *tgt_box = nullptr;
+    double tbox[6];
     if (p->voxel_size > 0) {  // pointcloud_alignment.py:22-23 on the frame and on the WHOLE resident model
         VoxelSegs V;
-        if ((rc = voxel_segments(ctx, ar, d_s, ns, p->voxel_size, V))) return rc;
+        if ((rc = voxel_segments(ctx, ar, d_s, ns, p->voxel_size, V, false, nullptr, nullptr, nullptr, frame_box))) return rc;
         double *d_sv = (double *)ar.get((size_t)V.nseg * 24), *d_cv = d_c ? (double *)ar.get((size_t)V.nseg * 24) : nullptr;
         if (ar.rc) return ar.rc;
         if ((rc = launch_voxel_mean(ctx, ar, false, d_s, V.idx, V.starts, V.nseg, ns, d_sv, V.sorted))) return rc;
@@ -3653,8 +3836,9 @@ int model_align_core(r3d_model *m, DevArena &ar, const r3d_align_params *p, doub
         d_c = d_cv;
         ms = V.nseg;
         double *d_tv = nullptr;
-        if ((rc = model_target_voxels(m, ar, p->voxel_size, &d_tv, &mt))) return rc;
+        if ((rc = model_target_voxels(m, ar, p->voxel_size, &d_tv, &mt, tbox))) return rc;
         d_t = d_tv;
+        tgt_box = tbox;   // the model's own box (the table keeps it): the voxel means lie inside it, no bounding-box pass for the search grid
     }
     // pointcloud_alignment.py:27-28 estimates normals on both clouds.  The point-to-point estimator never reads them and the
     // model's operator+= drops the frame's normals unless the model carries normals itself, so they are computed only where
@@ -3664,7 +3848,7 @@ int model_align_core(r3d_model *m, DevArena &ar, const r3d_align_params *p, doub
     if (want_sn && (rc = normals_core(ctx, ar, d_s, ms, p->normal_radius, p->normal_max_nn, nullptr, &d_sn))) return rc;
     if (ip->mode != MODE_P2P && (rc = normals_core(ctx, ar, d_t, mt, p->normal_radius, p->normal_max_nn, nullptr, &d_tn))) return rc;
     double T[16];
-    if ((rc = icp_core(ctx, ar, ip, d_s, ms, d_sn, d_t, mt, d_tn, nullptr, T, stats, t_begin))) return rc;  // :35-39, from identity
+    if ((rc = icp_core(ctx, ar, ip, d_s, ms, d_sn, d_t, mt, d_tn, nullptr, T, stats, t_begin, tgt_box))) return rc;  // :35-39, from identity
     memcpy(T4x4, T, sizeof T);
     double *d_o = (double *)ar.get((size_t)ms * 24), *d_on = d_sn ? (double *)ar.get((size_t)ms * 24) : nullptr;
     if (ar.rc) return ar.rc;
@@ -3672,8 +3856,19 @@ int model_align_core(r3d_model *m, DevArena &ar, const r3d_align_params *p, doub
     k_transform<<<nb, 256, 0, ctx->stream>>>(d_s, ms, to_rigid(T), 0, d_o);  // :42 source.transform
     if (d_sn) k_transform<<<nb, 256, 0, ctx->stream>>>(d_sn, ms, to_rigid(T), 1, d_on);
     R3D_HIP(ctx, hipGetLastError());
+    const int64_t n_before = m->n;
     if ((rc = model_append(m, d_o, d_c, d_on, ms, hipMemcpyDeviceToDevice))) return rc;   // main.py:49 combined += aligned
     if (appended) *appended = ms;
+    // the appended block's bounding box, for the next frame's table update: enqueued now, fetched with that call's first read-back
+    m->pend_host_ok = false;
+    m->pend_lo = m->pend_hi = 0;
+    if (p->voxel_size > 0 && ms > 0) {
+        if (!m->d_pend) {
+            hipError_t e = hipMalloc((void **)&m->d_pend, 64);
+            if (e != hipSuccess) { m->d_pend = nullptr; return R3D_OK; }       // no pending box: the next call computes it itself
+        }
+        if (cloud_bbox_enqueue_dn(ctx, ar, d_o, ms, nullptr, nullptr, nullptr, m->d_pend) == R3D_OK) { m->pend_lo = n_before; m->pend_hi = m->n; }
+    }
     return R3D_OK;
 }
 }  // namespace
@@ -3731,7 +3926,11 @@ int r3d_model_align_append_depth(r3d_model *m, const r3d_align_params *p, const 
     DevArena ar(ctx);
     double *d_p, *d_c;
     int64_t n;
-    if ((rc = backproject_core(ctx, ar, depth, w, h, stride, cam, color, color_stride, false, &d_p, &d_c, nullptr, &n))) return rc;
+    double fbox[6];
+    PinExtra pend;
+    if (m->d_pend && m->pend_hi > m->pend_lo && !m->pend_host_ok) { pend.host = m->pend_box; pend.dev = m->d_pend; pend.bytes = 48; }
+    if ((rc = backproject_core(ctx, ar, depth, w, h, stride, cam, color, color_stride, false, &d_p, &d_c, nullptr, &n, fbox, &pend))) return rc;
+    if (pend.host) m->pend_host_ok = true;
     if (frame_points) *frame_points = n;
     if (appended) *appended = 0;
     if (n == 0) {   // no valid pixel: a failed capture, skipped like main.py:53-54 (identity, empty statistics, nothing appended)
@@ -3739,7 +3938,7 @@ int r3d_model_align_append_depth(r3d_model *m, const r3d_align_params *p, const 
         if (stats) memset(stats, 0, sizeof *stats);
         return R3D_OK;
     }
-    return model_align_core(m, ar, p, d_p, d_c, n, T4x4, stats, appended, t_begin);
+    return model_align_core(m, ar, p, d_p, d_c, n, T4x4, stats, appended, t_begin, fbox);
 }
 
 int r3d_backproject_depth(r3d_ctx *ctx, const uint16_t *depth, int32_t w, int32_t h, int32_t stride, const r3d_depth_camera *cam,

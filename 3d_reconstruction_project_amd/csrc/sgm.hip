@@ -14,6 +14,7 @@
 // Lane mapping of every volume kernel: one wavefront owns ONE (row, column) disparity vector; lane l holds the
 // 2*NP consecutive disparities d = 2*NP*l .. 2*NP*l+2*NP-1 as NP packed int16x2 registers, so a wave reads or
 // writes 256*NP contiguous bytes per pixel and the d-1 / d+1 neighbours come from one DPP wave shift each way.
+#include <limits.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -969,6 +970,153 @@ __global__ void __launch_bounds__(64) k_hscan2(const int *__restrict__ cvol, int
             if (s - 2 >= 0) bwd_round(c2, c3, c1, s - 2);
             if (s - 3 >= 0) bwd_round(c3, c0, c2, s - 3);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_cost_fwd (R3D_SGM_IMPL=v5): block cost AND forward chain in one kernel -- the forward sweep no longer reads C from HBM
+// (2 GB per 8 MP map), and the cost arithmetic runs underneath the chain instead of in front of it.
+// The chain runs along image rows, so this kernel marches ALONG rows (k_cost2 marches down them): a workgroup owns RB = 4 output
+// rows for all W1 cost columns.  Wave 0 is the chain wave (the lane mapping of k_hscan2<4, 16, ...>: 16 lanes x 4 packed registers
+// per row, 4 rows); waves 1..3 are producers: producer p evaluates, for every third column, the Birchfield-Tomasi pixel cost of
+// the RB + 2*SH2 input rows (lane = disparity pair, so a column is one wave-wide vector per row; right-image records straight from
+// global memory: a wave reads one contiguous 1 KB window per row) and the VERTICAL box sums V of the RB output rows, which go to a
+// ring of columns in LDS.  The chain wave turns V into C by a sliding horizontal sum (C(x) = C(x-1) + V'(x+SW2) - V'(x-SW2-1),
+// exact in int16 arithmetic), writes C to HBM for the backward phase (k_hscan2<PHASE 2>), runs the L_left step, and saves the
+// checkpoints that phase needs.  One workgroup barrier per KR = 12 columns; producers run one round ahead.
+// V'(xv) = V(clamp(xv, 0, W1-1)): the replicated borders of the original's box filter in cost coordinates; rows clamp to the image.
+template <int SH2, bool PADDED>
+__global__ void __launch_bounds__(256) k_cost_fwd(const uint2 *__restrict__ recL, const uint2 *__restrict__ recR, SgmGeom g,
+                                                  int *__restrict__ cvol, int *__restrict__ hvol, int *__restrict__ ckpt) {
+    constexpr int NPL = 4, LPC = 16, DPW = NPL * LPC, RB = 4, RIN = RB + 2 * SH2, R = 2 * SH2 + 1, KR = 12, NPROD = 3, K = 16, CKS = DPW + 4;
+    constexpr int SLOTS = 2 * KR + 2 * SH2 + 2;          // columns alive at once: [x0 - SH2 - 1, x0 + 2 KR + SH2)
+    constexpr int RING = 256;                             // right-image records per input row kept in LDS (a window of 128 + 2 KR + SH2 is live)
+    static_assert(RIN * KR <= NPROD * 64, "one staged record per producer thread and round");
+    __shared__ int sV[SLOTS][RB][DPW];
+    // records of the right image, per input row: record i sits at index (i & 255) + 1; index 0 mirrors index 256, so that the pair
+    // (i - 1, i) a lane needs is always 16 contiguous bytes
+    __shared__ uint2 sR[RIN][RING + 2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int y0 = blockIdx.x * RB, W1 = g.W1;
+    const int nr = (W1 + KR - 1) / KR;                    // rounds of KR chain columns
+    auto slot_of = [&](int xv) { int v = (xv + SH2 + 1) % SLOTS; return v < 0 ? v + SLOTS : v; };
+    // highest right-image column the production of round t reads (t = -1: the prologue)
+    const int rofs = g.minX1 - g.minD;
+    auto rec_hi = [&](int t) { return min(KR * (t + 2) + SH2 - 1, W1 - 1) + rofs; };
+    auto put_rec = [&](int q, int i, uint2 v) {
+        sR[q][(i & (RING - 1)) + 1] = v;
+        if ((i & (RING - 1)) == RING - 1) sR[q][0] = v;
+    };
+    // all 256 threads: the window the prologue production reads
+    {
+        const int lo = rofs - (g.DP - 1) - 1, hi = rec_hi(-1), cnt = hi - lo + 1;
+        for (int u = threadIdx.x; u < RIN * cnt; u += 256) {
+            const int q = u / cnt, i = lo + u % cnt;
+            const int row = min(max(y0 - SH2 + q, 0), g.H - 1);
+            put_rec(q, i, recR[(size_t)row * g.W + min(max(i, 0), g.W - 1)]);
+        }
+    }
+    __syncthreads();
+    if (wave > 0) {
+        // ---------------------------------------------------------------- producers
+        const int p = wave - 1, u = threadIdx.x - 64;
+        const int sq = u / KR, sc = u % KR;               // the (input row, column) this thread stages each round
+        const int srow = min(max(y0 - SH2 + min(sq, RIN - 1), 0), g.H - 1);
+        int rowoff[RIN];                                  // record offset of each (clamped) input row
+#pragma unroll
+        for (int q = 0; q < RIN; q++) rowoff[q] = min(max(y0 - SH2 + q, 0), g.H - 1) * g.W;
+        auto produce = [&](int xv) {
+            const int xc = min(max(xv, 0), W1 - 1), xi = xc + g.minX1;
+            const int r = xi - g.minD - 2 * lane;        // right column of the even disparity of this lane's pair
+            const int ri = r & (RING - 1);               // the pair (r - 1, r) = sR[.][ri], sR[.][ri + 1]
+            int pix[RIN];
+#pragma unroll
+            for (int q = 0; q < RIN; q++) {
+                const uint2 lr = recL[rowoff[q] + xi];   // wave-uniform
+                const int Ug = (int)(lr.x & 255u) * 0x10001, Ug0 = (int)((lr.x >> 8) & 255u) * 0x10001, Ug1 = (int)((lr.x >> 16) & 255u) * 0x10001;
+                const int Ui = (int)(lr.x >> 24) * 0x10001, Ui0 = (int)(lr.y & 255u) * 0x10001, Ui1 = (int)((lr.y >> 8) & 255u) * 0x10001;
+                const uint2 B = sR[q][ri], A = sR[q][ri + 1];
+                const int Vg = __builtin_amdgcn_perm(B.x, A.x, 0x0c040c00), Vg0 = __builtin_amdgcn_perm(B.x, A.x, 0x0c050c01);
+                const int Vg1 = __builtin_amdgcn_perm(B.x, A.x, 0x0c060c02), Vi = __builtin_amdgcn_perm(B.x, A.x, 0x0c070c03);
+                const int Vi0 = __builtin_amdgcn_perm(B.y, A.y, 0x0c040c00), Vi1 = __builtin_amdgcn_perm(B.y, A.y, 0x0c050c01);
+                const int cg = bt_cost_pk(Ug, Ug0, Ug1, Vg, Vg0, Vg1);
+                const int ci = bt_cost_pk(Ui, Ui0, Ui1, Vi, Vi0, Vi1);
+                pix[q] = pk_add(cg, (ci >> 2) & 0x3fff3fff);
+            }
+            int v = 0;
+#pragma unroll
+            for (int q = 0; q < R; q++) v = pk_add(v, pix[q]);
+            int *dst = &sV[slot_of(xv)][0][lane];
+            dst[0] = v;
+#pragma unroll
+            for (int rr = 1; rr < RB; rr++) {
+                v = pk_add(pk_sub(v, pix[rr - 1]), pix[rr - 1 + R]);
+                dst[rr * DPW] = v;
+            }
+        };
+        // a round's new right-image records are fetched at its start and filed at its end: a whole round hides the load
+        auto stage_fetch = [&](int t, uint2 &v) -> int {   // returns the record index, or INT_MIN when this thread has none
+            const int i = rec_hi(t) + 1 + sc;
+            if (sq >= RIN || i > rec_hi(t + 1)) return INT_MIN;
+            v = recR[(size_t)srow * g.W + min(max(i, 0), g.W - 1)];
+            return i;
+        };
+        uint2 sv = make_uint2(0, 0);
+        int si = stage_fetch(-1, sv);
+        // prologue: everything round 0 reads: xv in [-SH2 - 1, KR + SH2) (the slot at -SH2 - 1 is only ever subtracted at x = 0,
+        // where the chain does not slide; it is produced anyway so that no slot is read before it was written)
+        for (int xv = -SH2 - 1 + p; xv < KR + SH2; xv += NPROD) produce(xv);
+        if (si != INT_MIN) put_rec(sq, si, sv);
+        __syncthreads();
+        for (int t = 0; t < nr; t++) {
+            const int x0 = KR * (t + 1) + SH2;           // what round t + 1 needs beyond what round t had
+            si = stage_fetch(t, sv);
+            if (t + 1 < nr)
+                for (int c = p; c < KR; c += NPROD) produce(x0 + c);
+            if (si != INT_MIN) put_rec(sq, si, sv);
+            __syncthreads();
+        }
+        return;
+    }
+    // -------------------------------------------------------------------- chain wave
+    const int k = lane % LPC, rl = lane / LPC;
+    const int yraw = y0 + rl;
+    const bool row_ok = yraw < g.H;
+    const int y = min(yraw, g.H - 1);
+    int *crow = cvol + (size_t)y * W1 * DPW + k * NPL;
+    int *hrow = hvol + (size_t)y * W1 * DPW + k * NPL;
+    const int nfull = W1 / K, P1pk = pk_dup(g.P1);
+    int *ckrow = ckpt + (size_t)yraw * (nfull + 1) * CKS, *ck = ckrow + k * NPL;
+    const bool valid = 2 * NPL * k < g.D, first = k == 0, last = k == LPC - 1;
+    int P[NPL], C[NPL], minp = 0;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) { P[j] = valid ? 0 : PADPK; C[j] = 0; }
+    auto ldv = [&](int xv) { return *(const int4 *)&sV[slot_of(xv)][rl][k * NPL]; };
+    __syncthreads();                                      // the producers' prologue (the window staging above was barrier one)
+    for (int t = 0; t < nr; t++) {
+        const int xe = min(KR * (t + 1), W1);
+        for (int x = KR * t; x < xe; x++) {
+            if (x == 0) {
+#pragma unroll
+                for (int i = -SH2; i <= SH2; i++) {
+                    const int4 v = ldv(i);
+                    C[0] = pk_add(C[0], v.x); C[1] = pk_add(C[1], v.y); C[2] = pk_add(C[2], v.z); C[3] = pk_add(C[3], v.w);
+                }
+            } else {
+                const int4 a = ldv(x + SH2), b = ldv(x - SH2 - 1);
+                C[0] = pk_sub(pk_add(C[0], a.x), b.x); C[1] = pk_sub(pk_add(C[1], a.y), b.y);
+                C[2] = pk_sub(pk_add(C[2], a.z), b.z); C[3] = pk_sub(pk_add(C[3], a.w), b.w);
+            }
+            if (row_ok) *(int4 *)(crow + (size_t)x * DPW) = make_int4(C[0], C[1], C[2], C[3]);
+            if ((x & (K - 1)) == 0 && x / K < nfull) {   // the state entering segment x / K (k_hscan2's checkpoint layout)
+                const int sidx = x / K;
+                *(int4 *)(ck + (size_t)sidx * CKS) = make_int4(P[0], P[1], P[2], P[3]);
+                if (first) ckrow[(size_t)sidx * CKS + DPW] = minp;
+            }
+            sgm_step_g<NPL, LPC, PADDED>(P, minp, C, P1pk, g.P2, first, last, valid);
+            if (x >= nfull * K && row_ok) *(int4 *)(hrow + (size_t)x * DPW) = make_int4(P[0], P[1], P[2], P[3]);   // tail: L_left parked
+        }
+        __syncthreads();
     }
 }
 
@@ -1979,7 +2127,7 @@ int derive_geom(r3d_ctx *ctx, const r3d_sgbm_params *p, int w, int h, SgmGeom &g
 // col_lo / col_hi: cost columns of a column slab (whole tiles: [ceil(col_lo / TO), ceil(col_hi / TO)) of the tile grid, so
 // consecutive slabs partition the tiles); col_hi < 0 = the whole width
 template <int LPC, int SH2, bool TRACK, bool VCH, int NWAVE>
-int launch_cost2_n(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st, int col_lo, int col_hi) {
+int launch_cost2_n(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st, int col_lo, int col_hi, bool spec_only = false) {
     constexpr int CW = 64 / LPC, TC = NWAVE * CW, TO = TC - 2 * SH2;
     if (TO <= 0) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "sgbm: tile too small for this block size");
     const int all_tiles = (g.W1 + TO - 1) / TO;
@@ -2004,8 +2152,12 @@ int launch_cost2_n(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t s
     if (nb < 1) nb = 1;
     int BAND = (g.H + nb - 1) / nb;
     if (BAND < 16) BAND = 16;
-    const int nMain = (g.H + BAND - 1) / BAND;
+    int nMain = (g.H + BAND - 1) / BAND;
     const int nSpec = SH2 > 0 ? 3 : 0;
+    if (spec_only) {      // only the stripe-top rows (cspec): the main volume comes from k_cost_fwd
+        if (nSpec == 0) return R3D_OK;
+        nMain = 0;
+    }
     int *maxc = (int *)ws.flags.p + 8;
     if (TRACK) R3D_HIP(ctx, hipMemsetAsync(maxc, 0, 4, st));
     k_cost2<LPC, SH2, TRACK, VCH, NWAVE><<<dim3(tiles, VCH ? 4 : nMain + nSpec), NWAVE * 64, 0, st>>>(
@@ -2022,34 +2174,51 @@ int launch_cost2_n(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t s
     return R3D_OK;
 }
 template <int LPC, int SH2, bool TRACK, bool VCH>
-int launch_cost2_t(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st, int col_lo, int col_hi) {
+int launch_cost2_t(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st, int col_lo, int col_hi, bool spec_only = false) {
     // 8 waves = 64-column tiles (2*SH2 halo columns); R3D_COST_NWAVE=4 selects 32-column tiles for A/B measurements
     static const bool four = [] { const char *e = getenv("R3D_COST_NWAVE"); return e && !strcmp(e, "4"); }();
     if constexpr (LPC == 8 && 4 * (64 / LPC) > 2 * SH2) {
-        if (four) return launch_cost2_n<LPC, SH2, TRACK, VCH, 4>(ctx, ws, g, st, col_lo, col_hi);
+        if (four) return launch_cost2_n<LPC, SH2, TRACK, VCH, 4>(ctx, ws, g, st, col_lo, col_hi, spec_only);
     }
-    return launch_cost2_n<LPC, SH2, TRACK, VCH, 8>(ctx, ws, g, st, col_lo, col_hi);
+    return launch_cost2_n<LPC, SH2, TRACK, VCH, 8>(ctx, ws, g, st, col_lo, col_hi, spec_only);
 }
 template <int LPC, bool VCH>
-int launch_cost2_l(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st, int col_lo, int col_hi) {
+int launch_cost2_l(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st, int col_lo, int col_hi, bool spec_only = false) {
     const bool track = (long)(2 * g.SH2 + 1) * (2 * g.SH2 + 1) * (2L * g.ftzero + 63) > 16383;
     switch (g.SH2) {
-        case 0: return launch_cost2_t<LPC, 0, false, VCH>(ctx, ws, g, st, col_lo, col_hi);
-        case 1: return launch_cost2_t<LPC, 1, false, VCH>(ctx, ws, g, st, col_lo, col_hi);
-        case 2: return launch_cost2_t<LPC, 2, false, VCH>(ctx, ws, g, st, col_lo, col_hi);
-        case 3: return track ? launch_cost2_t<LPC, 3, true, VCH>(ctx, ws, g, st, col_lo, col_hi) : launch_cost2_t<LPC, 3, false, VCH>(ctx, ws, g, st, col_lo, col_hi);
-        case 4: return track ? launch_cost2_t<LPC, 4, true, VCH>(ctx, ws, g, st, col_lo, col_hi) : launch_cost2_t<LPC, 4, false, VCH>(ctx, ws, g, st, col_lo, col_hi);
-        default: return launch_cost2_t<LPC, 5, true, VCH>(ctx, ws, g, st, col_lo, col_hi);
+        case 0: return launch_cost2_t<LPC, 0, false, VCH>(ctx, ws, g, st, col_lo, col_hi, spec_only);
+        case 1: return launch_cost2_t<LPC, 1, false, VCH>(ctx, ws, g, st, col_lo, col_hi, spec_only);
+        case 2: return launch_cost2_t<LPC, 2, false, VCH>(ctx, ws, g, st, col_lo, col_hi, spec_only);
+        case 3: return track ? launch_cost2_t<LPC, 3, true, VCH>(ctx, ws, g, st, col_lo, col_hi, spec_only) : launch_cost2_t<LPC, 3, false, VCH>(ctx, ws, g, st, col_lo, col_hi, spec_only);
+        case 4: return track ? launch_cost2_t<LPC, 4, true, VCH>(ctx, ws, g, st, col_lo, col_hi, spec_only) : launch_cost2_t<LPC, 4, false, VCH>(ctx, ws, g, st, col_lo, col_hi, spec_only);
+        default: return launch_cost2_t<LPC, 5, true, VCH>(ctx, ws, g, st, col_lo, col_hi, spec_only);
     }
 }
-int launch_cost2(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st, bool vch, int col_lo = 0, int col_hi = -1) {
+int launch_cost2(r3d_ctx *ctx, r3d_sgm_ws &ws, const SgmGeom &g, hipStream_t st, bool vch, int col_lo = 0, int col_hi = -1, bool spec_only = false) {
     if (vch) return g.NP == 1 ? launch_cost2_l<8, true>(ctx, ws, g, st, 0, -1) : launch_cost2_l<16, true>(ctx, ws, g, st, 0, -1);
     switch (g.DP) {  // LPC = DP / 16 lanes per column
-        case 32: return launch_cost2_l<2, false>(ctx, ws, g, st, col_lo, col_hi);
-        case 64: return launch_cost2_l<4, false>(ctx, ws, g, st, col_lo, col_hi);
-        case 128: return launch_cost2_l<8, false>(ctx, ws, g, st, col_lo, col_hi);
-        default: return launch_cost2_l<16, false>(ctx, ws, g, st, col_lo, col_hi);
+        case 32: return launch_cost2_l<2, false>(ctx, ws, g, st, col_lo, col_hi, spec_only);
+        case 64: return launch_cost2_l<4, false>(ctx, ws, g, st, col_lo, col_hi, spec_only);
+        case 128: return launch_cost2_l<8, false>(ctx, ws, g, st, col_lo, col_hi, spec_only);
+        default: return launch_cost2_l<16, false>(ctx, ws, g, st, col_lo, col_hi, spec_only);
     }
+}
+// k_cost_fwd (v5) for the DP = 128 layout: block cost along rows + forward chain + checkpoints
+int launch_cost_fwd(hipStream_t st, const r3d_sgm_ws &ws, const SgmGeom &g, int *cost, int *hsum, int *ckpt) {
+    const uint2 *rl = (const uint2 *)ws.rec_l.p, *rr = (const uint2 *)ws.rec_r.p;
+    const int nwg = (g.H + 3) / 4;
+    const bool padded = g.D != g.DP;
+#define R3D_CF(S)                                                                                           \
+    case S:                                                                                                 \
+        if (padded) k_cost_fwd<S, true><<<nwg, 256, 0, st>>>(rl, rr, g, cost, hsum, ckpt);                    \
+        else k_cost_fwd<S, false><<<nwg, 256, 0, st>>>(rl, rr, g, cost, hsum, ckpt);                          \
+        break;
+    switch (g.SH2) {
+        R3D_CF(0) R3D_CF(1) R3D_CF(2) R3D_CF(3) R3D_CF(4) R3D_CF(5)
+        default: return -1;
+    }
+#undef R3D_CF
+    return (int)hipGetLastError();
 }
 
 
@@ -2253,7 +2422,7 @@ static int sgm_run_impl(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_p
     // implementation generations kept side by side for A/B measurements: R3D_SGM_IMPL = v1 | v2 (default) | v3.
     // v3 (L_top fused into the cost kernel, WTA fused into hscan) moves 2.7 GB less but measured 5.0 ms against 3.45 ms
     // for v2 on C2, so it is not the default.
-    static const int impl = [] { const char *e = getenv("R3D_SGM_IMPL"); return !e ? 2 : !strcmp(e, "v1") ? 1 : !strcmp(e, "v3") ? 3 : !strcmp(e, "v4") ? 4 : 2; }();
+    static const int impl = [] { const char *e = getenv("R3D_SGM_IMPL"); return !e ? 2 : !strcmp(e, "v1") ? 1 : !strcmp(e, "v3") ? 3 : !strcmp(e, "v4") ? 4 : !strcmp(e, "v5") ? 5 : 2; }();
     const bool use_v1 = impl == 1;
     ctx->last_impl = impl;
     const float inv_a = 1.0f / (float)(100 - g.uniq);
@@ -2319,6 +2488,25 @@ static int sgm_run_impl(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_p
     static const bool lowreg = [] { const char *e = getenv("R3D_SGM_FWD"); return !(e && !strcmp(e, "wide")); }();
     const bool track = (long)(2 * g.SH2 + 1) * (2 * g.SH2 + 1) * (2L * g.ftzero + 63) > 16383;
     const bool overlapped = !use_v1 && n_slabs >= 2 && g.DP == 128 && !rows2_env && !track && g.W1 / KOV >= 8 * n_slabs;
+    // v5: cost + forward chain fused (k_cost_fwd), then the backward phase of k_hscan2; D <= 128 layouts with 128 slots only, and only
+    // where the static envelope bound holds (no TRACK pass); otherwise the v2 kernels below
+    const bool fused_fwd = impl == 5 && g.DP == 128 && !track && g.W1 / 16 >= 1;
+    if (fused_fwd) {
+        constexpr int KF = 16;
+        const int nfull = g.W1 / KF, nwaves = (h + 3) / 4;
+        const bool padded = g.D != g.DP;
+        if ((rc = r3d_reserve(ctx, ws.ckpt, (size_t)(h + 8) * (nfull + 1) * (NPW + 4) * 4))) return rc;
+        const int *cp = (const int *)ws.cost.p;
+        int *hp = (int *)ws.hsum.p, *kp = (int *)ws.ckpt.p;
+        r3d_prof_mark(ctx, ws, st, "cost_fwd");
+        if ((rc = launch_cost2(ctx, ws, g, st, false, 0, -1, true))) return rc;        // stripe-top rows (cspec) for the vertical pass
+        if (int e = launch_cost_fwd(st, ws, g, (int *)ws.cost.p, hp, kp))
+            return e < 0 ? r3d_fail(ctx, R3D_E_UNSUPPORTED, "k_cost_fwd: no instantiation for this block size")
+                         : r3d_fail(ctx, R3D_E_HIP, "k_cost_fwd launch failed: %s", hipGetErrorString((hipError_t)e));
+        r3d_prof_mark(ctx, ws, st, "hscan_bwd");
+        if (padded) k_hscan2<4, 16, KF, true, 2><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, nfull);
+        else k_hscan2<4, 16, KF, false, 2><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, nfull);
+    } else
     if (overlapped) {
         if (!ws.aux) R3D_HIP(ctx, hipStreamCreateWithFlags(&ws.aux, hipStreamNonBlocking));
         if (!ws.slab_ev[0])

@@ -37,9 +37,10 @@ ALG_BYTES = {
     "hscan_bwd": 2 * W1 * H * D,              # same write, issued by the backward-phase launch when the phases are separate
     "vscan_wta": 2 * W1 * H * D + 4 * W * H,  # the one compulsory volume READ + disparity/cost out
     "cost": 2 * W * H,                        # reads both images; the cost volume itself is not algorithmic
+    "cost_fwd": 2 * W * H,                    # v5: cost along rows + forward chain in one kernel (images in; C out is not algorithmic)
 }
-KERNEL_OF = {"cost": "k_cost2", "hscan": "k_hscan2", "hscan_bwd": "k_hscan2", "vscan_wta": "k_vscan2", "prefilter": "k_prefilter",
-             "lrcheck": "k_lrcheck", "median3": "k_median3"}
+KERNEL_OF = {"cost": "k_cost2", "cost_fwd": "k_cost_fwd", "hscan": "k_hscan2", "hscan_bwd": "k_hscan2", "vscan_wta": "k_vscan2",
+             "prefilter": "k_prefilter", "lrcheck": "k_lrcheck", "median3": "k_median3"}
 
 
 def bench_gicp(r3d, ctx, n=1_000_000, iters=20, cpu=True):
@@ -594,7 +595,7 @@ def main():
         prof_ = dict(prof)
         # R3D_SGM_OVERLAP builds: the cost kernel runs slab by slab underneath the forward phase (bracket "cost+hscan_fwd"), the
         # backward phase is its own launch ("hscan_bwd"); the horizontal scan as a whole is what the roofline is quoted on
-        overlapped = "hscan_bwd" in prof_
+        overlapped = "hscan_bwd" in prof_ and "cost+hscan_fwd" in prof_
         if overlapped:
             prof_["hscan"] = prof_["cost+hscan_fwd"] + prof_["hscan_bwd"]
         single = {k: v for k, v in prof_.items() if k not in ("cost+hscan_fwd", "hscan_bwd")} if overlapped else prof_

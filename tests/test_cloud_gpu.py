@@ -348,7 +348,11 @@ def test_non_finite_coordinates_are_refused(r3d):
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_fused_align_call_equals_chained_entry_points(r3d, mode):
     """r3d_align_point_clouds (one device-resident call) == voxel_down_sample x2 -> estimate_normals x2 -> registration ->
-    transform through the separate host-buffer entry points: same kernels, so bit-identical outputs."""
+    transform through the separate host-buffer entry points: same kernels, same correspondences, same iteration counts.  Since
+    round 4 the fused call lays the registration's search grid out in the bounding box of the target BEFORE down-sampling (it has
+    that box from the voxel grid and saves a bounding-box round trip; the chained call only ever sees the down-sampled target), so
+    the sources are visited in a different order and the 29 sums differ in their last bits: transforms equal to 1e-12, not bit for
+    bit; everything that does not pass through those sums (voxel means, colours) stays exact."""
     ops = r3d.cloud_ops
     src, tgt = _frame("output84", 10), _frame("output84", 8)
     rng = np.random.default_rng(0)
@@ -358,10 +362,10 @@ def test_fused_align_call_equals_chained_entry_points(r3d, mode):
     tp, _, _ = ops.voxel_down_sample(tgt, 0.01)
     sn, tn = ops.estimate_normals(sp, 0.02, 30), ops.estimate_normals(tp, 0.02, 30)
     res = ops.registration(sp, tp, 0.02, np.eye(4), mode, 40, 1e-6, 1e-6, sn, tn)
-    np.testing.assert_array_equal(got["T"], res["T"])
+    assert np.abs(got["T"] - res["T"]).max() < 1e-12
     assert got["iterations"] == res["iterations"] and got["correspondences"] == res["correspondences"]
-    np.testing.assert_array_equal(got["points"], ops.transform_points(sp, res["T"]))
-    np.testing.assert_array_equal(got["normals"], ops.transform_points(sn, res["T"], rotate_only=True))
+    np.testing.assert_array_equal(got["points"], ops.transform_points(sp, got["T"]))
+    np.testing.assert_array_equal(got["normals"], ops.transform_points(sn, got["T"], rotate_only=True))
     np.testing.assert_array_equal(got["colors"], sc)
     # no down-sampling, no normals: plain point-to-point on the raw clouds
     if mode == 0:

@@ -188,7 +188,7 @@ def test_randomised_parameter_sweep(r3d):
         assert np.array_equal(got, want), f"case {case}: W={W} H={H} D={D} {kw}: {(got != want).sum()} pixels differ"
 
 
-@pytest.mark.parametrize("impl", ["v1", "v2", "v3", "v4"])
+@pytest.mark.parametrize("impl", ["v1", "v2", "v3", "v4", "v5"])
 def test_alternative_kernel_generations_stay_bit_exact(impl):
     """R3D_SGM_IMPL selects the kernel generation at library load: v2 reads the cost volume in its vertical pass, v4
     recomputes it there (k_vscan3); v1 and v3 are kept for A/B measurements."""
