@@ -47,6 +47,11 @@ struct GridView {
     // optional packed copy for the default search (nn_block_q10): one dword per sorted point = 10-bit offsets inside its own
     // cell (x | y << 10 | z << 20) and the low two bits of its cell x index (<< 30); n + 4 entries
     const unsigned *q10;
+    // optional (registration loop): reach[coarse cell] != 0 iff some point lies in the 3x3x3 block of COARSE cells (rs fine cells
+    // on a side) around it.  A query whose coarse cell reads 0 has no point within rs fine cells in any direction, i.e. none within
+    // the correspondence radius (rs >= ceil(radius / cell)): its search is skipped outright, with the result it would have had.
+    const unsigned char *reach;
+    int rs, rnx, rny, rnz;
 };
 
 __device__ __forceinline__ int cell_coord(double v, double o, double inv) { return (int)floor((v - o) * inv); }
@@ -1202,6 +1207,25 @@ __device__ __forceinline__ void nn_block_top4(const GridView &g, double px, doub
     }
 }
 
+// reach bitmap of a search grid (GridView::reach): coarse occupancy, then a 3-tap maximum along x, y and z
+__global__ void __launch_bounds__(256) k_reach_mark(GridView g, int64_t n, int rs, int rnx, int rny, int rnz, unsigned char *__restrict__ occ) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int cx = min(max(cell_coord(g.pts[i * 3], g.ox, g.inv_cell), 0), g.nx - 1) / rs;
+    const int cy = min(max(cell_coord(g.pts[i * 3 + 1], g.oy, g.inv_cell), 0), g.ny - 1) / rs;
+    const int cz = min(max(cell_coord(g.pts[i * 3 + 2], g.oz, g.inv_cell), 0), g.nz - 1) / rs;
+    occ[((int64_t)cz * rny + cy) * rnx + cx] = 1;
+}
+__global__ void __launch_bounds__(256) k_reach_dilate(const unsigned char *__restrict__ in, unsigned char *__restrict__ out, int64_t n, int64_t stride, int dim) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t pos = (i / stride) % dim;            // coordinate along the filtered axis
+    unsigned char v = in[i];
+    if (pos > 0) v |= in[i - stride];
+    if (pos + 1 < dim) v |= in[i + stride];
+    out[i] = v;
+}
+
 __global__ void __launch_bounds__(256) k_soa_f32(const double *__restrict__ pts, int64_t n, float *__restrict__ fx, float *__restrict__ fy,
                                                  float *__restrict__ fz) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1434,6 +1458,15 @@ __device__ __forceinline__ void nn_outer_shells(const GridView &g, double px, do
     }
 }
 
+// true when the reach bitmap proves that no target point lies within rs fine cells of the query's cell in any direction (so none
+// within the correspondence radius).  Queries outside the grid are measured from the nearest grid cell: conservative.
+__device__ __forceinline__ bool icp_out_of_reach(const GridView &g, int cx, int cy, int cz) {
+    if (!g.reach) return false;
+    if (cx < -g.rs || cy < -g.rs || cz < -g.rs || cx >= g.nx + g.rs || cy >= g.ny + g.rs || cz >= g.nz + g.rs) return true;   // beyond the grid by more than the radius
+    const int qx = min(max(cx, 0), g.nx - 1) / g.rs, qy = min(max(cy, 0), g.ny - 1) / g.rs, qz = min(max(cz, 0), g.nz - 1) / g.rs;
+    return g.reach[((int64_t)qz * g.rny + qy) * g.rnx + qx] == 0;
+}
+
 // adds one correspondence (source point i at p, target slot bi at squared distance `best`) to the accumulators
 template <int MODE>
 __device__ __forceinline__ void icp_accumulate(const GridView &g, const double *__restrict__ src_n, const double *__restrict__ tgt_n,
@@ -1563,10 +1596,12 @@ __global__ void __launch_bounds__(ICP_BLOCK, 3) k_icp_eval(GridView g, const dou
         const int cx = cell_coord(px, g.ox, g.inv_cell), cy = cell_coord(py, g.oy, g.inv_cell), cz = cell_coord(pz, g.oz, g.inv_cell);
         double best = r2;
         int bi = -1;
-        if (SEARCH == SEARCH_Q10) nn_block_q10(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun);
-        else if (SEARCH == SEARCH_F32) nn_block_top4(g, px, py, pz, cx, cy, cz, best, bi);
-        else nn_block_global(g, px, py, pz, cx, cy, cz, best, bi);
-        nn_outer_shells(g, px, py, pz, cx, cy, cz, smax, best, bi);
+        if (!icp_out_of_reach(g, cx, cy, cz)) {
+            if (SEARCH == SEARCH_Q10) nn_block_q10(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun);
+            else if (SEARCH == SEARCH_F32) nn_block_top4(g, px, py, pz, cx, cy, cz, best, bi);
+            else nn_block_global(g, px, py, pz, cx, cy, cz, best, bi);
+            nn_outer_shells(g, px, py, pz, cx, cy, cz, smax, best, bi);
+        }
         if (corr) corr[i] = bi >= 0 ? g.idx[bi] : -1;
         if (bi >= 0) icp_accumulate<MODE>(g, src_n, tgt_n, i, T, eps, px, py, pz, best, bi, acc);
     }
@@ -1616,10 +1651,12 @@ __global__ void __launch_bounds__(ICP_BLOCK, 4) k_icp_search(GridView g, const d
         const int cx = cell_coord(px, g.ox, g.inv_cell), cy = cell_coord(py, g.oy, g.inv_cell), cz = cell_coord(pz, g.oz, g.inv_cell);
         double best = r2;
         int bi = -1;
-        if (SEARCH == SEARCH_Q10) nn_block_q10(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun);
-        else if (SEARCH == SEARCH_F32) nn_block_top4(g, px, py, pz, cx, cy, cz, best, bi);
-        else nn_block_global(g, px, py, pz, cx, cy, cz, best, bi);
-        nn_outer_shells(g, px, py, pz, cx, cy, cz, smax, best, bi);
+        if (!icp_out_of_reach(g, cx, cy, cz)) {
+            if (SEARCH == SEARCH_Q10) nn_block_q10(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun);
+            else if (SEARCH == SEARCH_F32) nn_block_top4(g, px, py, pz, cx, cy, cz, best, bi);
+            else nn_block_global(g, px, py, pz, cx, cy, cz, best, bi);
+            nn_outer_shells(g, px, py, pz, cx, cy, cz, smax, best, bi);
+        }
         nn[i] = bi;
     }
 }
@@ -2331,8 +2368,12 @@ int sort_by_cell(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, con
 // enclosing[6] (optional): a box known to contain every point (e.g. the bounding box of the cloud these points are voxel means
 // of): used, slightly widened, instead of a bounding-box pass and its host round trip.  A search grid's origin and extent decide
 // only which cell a point is filed under; what the searches return does not depend on them.
+// spacing_hint (optional): the cloud is a voxel-down-sampled surface with this voxel size, so a cell of side c holds about
+// (c / spacing)^2 points -- used instead of the bounding-box estimate below, which is off by 3-6x on a room-sized scan (the box's
+// faces are not the surface) and then picks cells of HALF the correspondence radius: every query whose nearest point is further
+// than one such cell -- most of them while a scan frame is still misaligned by a centimetre -- walks the 98 cells of shell 2.
 int grid_build(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, double cell_hint, double target_occ, Grid &G, bool dense_table = false,
-               const double *enclosing = nullptr) {
+               const double *enclosing = nullptr, double spacing_hint = 0) {
     if (n <= 0) return r3d_fail(ctx, R3D_E_BADARG, "grid: empty cloud");
     if (n > 0x7fffffff) return r3d_fail(ctx, R3D_E_UNSUPPORTED, "grid: more than 2^31-1 points");
     int rc;
@@ -2352,7 +2393,8 @@ int grid_build(r3d_ctx *ctx, DevArena &ar, const double *d_pts, int64_t n, doubl
     if (cell_hint > 0 && target_occ > 0) {
         // estimate occupancy at cell_hint assuming a 2-manifold: area ~ n * spacing^2, spacing from bbox area
         const double area = 2.0 * (ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2]) / 2.0;  // rough
-        const double per_cell = (double)n * cell_hint * cell_hint / std::max(area, 1e-30);
+        const double per_cell = spacing_hint > 0 ? (cell_hint / spacing_hint) * (cell_hint / spacing_hint)
+                                                 : (double)n * cell_hint * cell_hint / std::max(area, 1e-30);
         int m = (int)std::floor(std::sqrt(std::max(per_cell / target_occ, 1.0)));
         m = std::max(1, std::min(m, 16));
         cell = cell_hint / m;
@@ -2883,12 +2925,13 @@ int normals_core(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, doubl
 // allows it); everything below r3d_icp's argument checks and uploads
 static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double *d_s, int64_t ns, double *d_sn, double *d_t, int64_t nt,
                     double *d_tn, const double *init4x4, double *T4x4, r3d_icp_stats *stats,
-                    std::chrono::steady_clock::time_point t_begin, const double *tgt_enclosing = nullptr /* grid_build's `enclosing` */) {
+                    std::chrono::steady_clock::time_point t_begin, const double *tgt_enclosing = nullptr /* grid_build's `enclosing` */,
+                    double tgt_spacing = 0 /* grid_build's `spacing_hint`: voxel size the target was down-sampled with */) {
     int rc;
     Grid G;
     double occ = 3.0;   // points per occupied cell the search grid aims at (R3D_ICP_OCC: A/B)
     if (const char *oe = getenv("R3D_ICP_OCC")) { const double v = atof(oe); if (v >= 0.5 && v <= 64) occ = v; }
-    if ((rc = grid_build(ctx, ar, d_t, nt, p->max_correspondence_distance, occ, G, true, tgt_enclosing))) return rc;   // dense table: one load per row in the loop
+    if ((rc = grid_build(ctx, ar, d_t, nt, p->max_correspondence_distance, occ, G, true, tgt_enclosing, tgt_spacing))) return rc;   // dense table: one load per row in the loop
     // float32 copy for the two-stage search (R3D_ICP_IMPL=exact: all-float64 search, for A/B).  fe = 2 x bound on
     // |float distance - exact distance|: both end points are rounded to float (relative 2^-24 per coordinate), times a
     // safety factor of 2; skipped (exact search) when the coordinates are so large that the margin stops filtering.
@@ -2913,6 +2956,29 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
             R3D_HIP(ctx, hipGetLastError());
             G.v.fx = f; G.v.fy = f + (nt + 4); G.v.fz = f + 2 * (nt + 4);
             G.v.fe = (float)(4.0 * e);
+        }
+    }
+    // reach bitmap (GridView::reach): where the search walks outer shells (cell < radius) a query with NO target point within the
+    // radius pays for the whole (2 s + 1)^3 neighbourhood, and the bitmap lets it leave at once.  MEASURED on the 76-frame scan:
+    // no effect (397 vs 397 ms of loops) -- there the walkers are queries whose nearest point lies between one cell and the radius,
+    // not queries far from the model; what helped is a cell as large as the radius (grid_build's spacing_hint: 390 -> 252 ms).
+    // Off by default (R3D_ICP_REACH=1 builds it: three small kernels per registration).
+    {
+        static const bool reach_on = [] { const char *e = getenv("R3D_ICP_REACH"); return e && !strcmp(e, "1"); }();
+        const int rs = (int)std::ceil(p->max_correspondence_distance * G.v.inv_cell);   // = the kernels' smax
+        if (reach_on && rs >= 2) {
+            const int rnx = (G.v.nx + rs - 1) / rs, rny = (G.v.ny + rs - 1) / rs, rnz = (G.v.nz + rs - 1) / rs;
+            const int64_t rn = (int64_t)rnx * rny * rnz;
+            unsigned char *ra = (unsigned char *)ar.get((size_t)rn), *rb = (unsigned char *)ar.get((size_t)rn);
+            if (ar.rc) return ar.rc;
+            R3D_HIP(ctx, hipMemsetAsync(ra, 0, (size_t)rn, ctx->stream));
+            k_reach_mark<<<(unsigned)((nt + 255) / 256), 256, 0, ctx->stream>>>(G.v, nt, rs, rnx, rny, rnz, ra);
+            const unsigned nbr = (unsigned)((rn + 255) / 256);
+            k_reach_dilate<<<nbr, 256, 0, ctx->stream>>>(ra, rb, rn, 1, rnx);
+            k_reach_dilate<<<nbr, 256, 0, ctx->stream>>>(rb, ra, rn, rnx, rny);
+            k_reach_dilate<<<nbr, 256, 0, ctx->stream>>>(ra, rb, rn, (int64_t)rnx * rny, rnz);
+            R3D_HIP(ctx, hipGetLastError());
+            G.v.reach = rb; G.v.rs = rs; G.v.rnx = rnx; G.v.rny = rny; G.v.rnz = rnz;
         }
     }
     double *d_tns = nullptr;
@@ -3327,7 +3393,7 @@ int r3d_align_point_clouds(r3d_ctx *ctx, const r3d_align_params *p, const double
         if ((rc = normals_core(ctx, ar, d_t, mt, p->normal_radius, p->normal_max_nn, nullptr, &d_tn))) return rc;
     }
     double T[16];
-    if ((rc = icp_core(ctx, ar, ip, d_s, ms, d_sn, d_t, mt, d_tn, init4x4, T, stats, t_begin, tgt_box))) return rc;  // :35-39
+    if ((rc = icp_core(ctx, ar, ip, d_s, ms, d_sn, d_t, mt, d_tn, init4x4, T, stats, t_begin, tgt_box, p->voxel_size > 0 ? p->voxel_size : 0))) return rc;  // :35-39
     memcpy(T4x4, T, sizeof T);
     double *d_o = (double *)ar.get((size_t)ms * 24), *d_on = d_sn ? (double *)ar.get((size_t)ms * 24) : nullptr;
     if (ar.rc) return ar.rc;
@@ -3848,7 +3914,7 @@ int model_align_core(r3d_model *m, DevArena &ar, const r3d_align_params *p, doub
     if (want_sn && (rc = normals_core(ctx, ar, d_s, ms, p->normal_radius, p->normal_max_nn, nullptr, &d_sn))) return rc;
     if (ip->mode != MODE_P2P && (rc = normals_core(ctx, ar, d_t, mt, p->normal_radius, p->normal_max_nn, nullptr, &d_tn))) return rc;
     double T[16];
-    if ((rc = icp_core(ctx, ar, ip, d_s, ms, d_sn, d_t, mt, d_tn, nullptr, T, stats, t_begin, tgt_box))) return rc;  // :35-39, from identity
+    if ((rc = icp_core(ctx, ar, ip, d_s, ms, d_sn, d_t, mt, d_tn, nullptr, T, stats, t_begin, tgt_box, p->voxel_size > 0 ? p->voxel_size : 0))) return rc;  // :35-39, from identity
     memcpy(T4x4, T, sizeof T);
     double *d_o = (double *)ar.get((size_t)ms * 24), *d_on = d_sn ? (double *)ar.get((size_t)ms * 24) : nullptr;
     if (ar.rc) return ar.rc;

@@ -989,17 +989,26 @@ template <int SH2, bool PADDED>
 __global__ void __launch_bounds__(256) k_cost_fwd(const uint2 *__restrict__ recL, const uint2 *__restrict__ recR, SgmGeom g,
                                                   int *__restrict__ cvol, int *__restrict__ hvol, int *__restrict__ ckpt) {
     constexpr int NPL = 4, LPC = 16, DPW = NPL * LPC, RB = 4, RIN = RB + 2 * SH2, R = 2 * SH2 + 1, KR = 12, NPROD = 3, K = 16, CKS = DPW + 4;
-    constexpr int SLOTS = 2 * KR + 2 * SH2 + 2;          // columns alive at once: [x0 - SH2 - 1, x0 + 2 KR + SH2)
+    constexpr int CPP = KR / NPROD;                       // columns a producer evaluates per round
+    constexpr int SLOTS = 2 * KR + 2 * SH2 + 1;          // V columns alive at once: [x0 - SH2 - 1, x0 + 2 KR + SH2)
     constexpr int RING = 256;                             // right-image records per input row kept in LDS (a window of 128 + 2 KR + SH2 is live)
-    static_assert(RIN * KR <= NPROD * 64, "one staged record per producer thread and round");
+    constexpr int LSLOTS = 2 * KR + 2 * SH2 + 2;          // left-image columns kept in LDS (the prologue's KR + 2 SH2 + 1 plus one round being filed)
+    // LDS per workgroup at SH2 = 2: 29 KB + 16.1 KB + 5.6 KB = 50.7 KB: three workgroups per CU (612 workgroups at C2 = 2.4 per CU)
+    constexpr int NITEM = 2 * RIN * KR, NST = (NITEM + NPROD * 64 - 1) / (NPROD * 64);   // staged records per round; per producer thread
+    static_assert(KR % NPROD == 0 && KR + 2 * SH2 + 1 + KR <= LSLOTS, "round geometry");
     __shared__ int sV[SLOTS][RB][DPW];
     // records of the right image, per input row: record i sits at index (i & 255) + 1; index 0 mirrors index 256, so that the pair
     // (i - 1, i) a lane needs is always 16 contiguous bytes
     __shared__ uint2 sR[RIN][RING + 2];
+    // left image: per input row and column the six Birchfield-Tomasi quantities, each already splatted into both halves of a word
+    // (read by every lane of a producer at the same address: a broadcast)
+    __shared__ int sL[RIN][LSLOTS][6];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int y0 = blockIdx.x * RB, W1 = g.W1;
     const int nr = (W1 + KR - 1) / KR;                    // rounds of KR chain columns
     auto slot_of = [&](int xv) { int v = (xv + SH2 + 1) % SLOTS; return v < 0 ? v + SLOTS : v; };
+    auto lslot_of = [&](int xv) { int v = (xv + SH2 + 1) % LSLOTS; return v < 0 ? v + LSLOTS : v; };
+    auto row_of = [&](int q) { return min(max(y0 - SH2 + q, 0), g.H - 1); };
     // highest right-image column the production of round t reads (t = -1: the prologue)
     const int rofs = g.minX1 - g.minD;
     auto rec_hi = [&](int t) { return min(KR * (t + 2) + SH2 - 1, W1 - 1) + rofs; };
@@ -1007,46 +1016,59 @@ __global__ void __launch_bounds__(256) k_cost_fwd(const uint2 *__restrict__ recL
         sR[q][(i & (RING - 1)) + 1] = v;
         if ((i & (RING - 1)) == RING - 1) sR[q][0] = v;
     };
-    // all 256 threads: the window the prologue production reads
+    auto get_left = [&](int q, int xv) { return recL[(size_t)row_of(q) * g.W + min(max(xv, 0), W1 - 1) + g.minX1]; };
+    auto put_left = [&](int q, int xv, uint2 lr) {
+        int2 *o = (int2 *)&sL[q][lslot_of(xv)][0];
+        o[0] = make_int2((int)(lr.x & 255u) * 0x10001, (int)((lr.x >> 8) & 255u) * 0x10001);
+        o[1] = make_int2((int)((lr.x >> 16) & 255u) * 0x10001, (int)(lr.x >> 24) * 0x10001);
+        o[2] = make_int2((int)(lr.y & 255u) * 0x10001, (int)((lr.y >> 8) & 255u) * 0x10001);
+    };
+    // all 256 threads: what the prologue production reads (right-image window, left columns [-SH2 - 1, KR + SH2))
     {
         const int lo = rofs - (g.DP - 1) - 1, hi = rec_hi(-1), cnt = hi - lo + 1;
         for (int u = threadIdx.x; u < RIN * cnt; u += 256) {
             const int q = u / cnt, i = lo + u % cnt;
-            const int row = min(max(y0 - SH2 + q, 0), g.H - 1);
-            put_rec(q, i, recR[(size_t)row * g.W + min(max(i, 0), g.W - 1)]);
+            put_rec(q, i, recR[(size_t)row_of(q) * g.W + min(max(i, 0), g.W - 1)]);
+        }
+        constexpr int LC = KR + 2 * SH2 + 1;
+        for (int u = threadIdx.x; u < RIN * LC; u += 256) {
+            const int q = u / LC, xv = -SH2 - 1 + u % LC;
+            put_left(q, xv, get_left(q, xv));
         }
     }
     __syncthreads();
     if (wave > 0) {
         // ---------------------------------------------------------------- producers
-        const int p = wave - 1, u = threadIdx.x - 64;
-        const int sq = u / KR, sc = u % KR;               // the (input row, column) this thread stages each round
-        const int srow = min(max(y0 - SH2 + min(sq, RIN - 1), 0), g.H - 1);
-        int rowoff[RIN];                                  // record offset of each (clamped) input row
-#pragma unroll
-        for (int q = 0; q < RIN; q++) rowoff[q] = min(max(y0 - SH2 + q, 0), g.H - 1) * g.W;
-        auto produce = [&](int xv) {
+        const int p = wave - 1, u0 = threadIdx.x - 64;
+        // evaluation of one column, in two halves so that the LDS reads of the next column are in flight during the arithmetic of this one
+        struct Col { uint2 A[RIN], B[RIN]; int xv; };   // (the left-image words are the same in every lane: read where they are used)
+        auto load_col = [&](int xv, Col &c) {
             const int xc = min(max(xv, 0), W1 - 1), xi = xc + g.minX1;
             const int r = xi - g.minD - 2 * lane;        // right column of the even disparity of this lane's pair
             const int ri = r & (RING - 1);               // the pair (r - 1, r) = sR[.][ri], sR[.][ri + 1]
+            c.xv = xv;
+#pragma unroll
+            for (int q = 0; q < RIN; q++) { c.B[q] = sR[q][ri]; c.A[q] = sR[q][ri + 1]; }
+        };
+        auto compute_col = [&](const Col &c) {
             int pix[RIN];
+            const int ls = lslot_of(c.xv);
 #pragma unroll
             for (int q = 0; q < RIN; q++) {
-                const uint2 lr = recL[rowoff[q] + xi];   // wave-uniform
-                const int Ug = (int)(lr.x & 255u) * 0x10001, Ug0 = (int)((lr.x >> 8) & 255u) * 0x10001, Ug1 = (int)((lr.x >> 16) & 255u) * 0x10001;
-                const int Ui = (int)(lr.x >> 24) * 0x10001, Ui0 = (int)(lr.y & 255u) * 0x10001, Ui1 = (int)((lr.y >> 8) & 255u) * 0x10001;
-                const uint2 B = sR[q][ri], A = sR[q][ri + 1];
+                const uint2 A = c.A[q], B = c.B[q];
+                const int2 *lp = (const int2 *)&sL[q][ls][0];
+                const int2 l0 = lp[0], l1 = lp[1], l2 = lp[2];           // (Ug, Ug0) (Ug1, Ui) (Ui0, Ui1): one address for the whole wave
                 const int Vg = __builtin_amdgcn_perm(B.x, A.x, 0x0c040c00), Vg0 = __builtin_amdgcn_perm(B.x, A.x, 0x0c050c01);
                 const int Vg1 = __builtin_amdgcn_perm(B.x, A.x, 0x0c060c02), Vi = __builtin_amdgcn_perm(B.x, A.x, 0x0c070c03);
                 const int Vi0 = __builtin_amdgcn_perm(B.y, A.y, 0x0c040c00), Vi1 = __builtin_amdgcn_perm(B.y, A.y, 0x0c050c01);
-                const int cg = bt_cost_pk(Ug, Ug0, Ug1, Vg, Vg0, Vg1);
-                const int ci = bt_cost_pk(Ui, Ui0, Ui1, Vi, Vi0, Vi1);
+                const int cg = bt_cost_pk(l0.x, l0.y, l1.x, Vg, Vg0, Vg1);
+                const int ci = bt_cost_pk(l1.y, l2.x, l2.y, Vi, Vi0, Vi1);
                 pix[q] = pk_add(cg, (ci >> 2) & 0x3fff3fff);
             }
             int v = 0;
 #pragma unroll
             for (int q = 0; q < R; q++) v = pk_add(v, pix[q]);
-            int *dst = &sV[slot_of(xv)][0][lane];
+            int *dst = &sV[slot_of(c.xv)][0][lane];
             dst[0] = v;
 #pragma unroll
             for (int rr = 1; rr < RB; rr++) {
@@ -1054,26 +1076,60 @@ __global__ void __launch_bounds__(256) k_cost_fwd(const uint2 *__restrict__ recL
                 dst[rr * DPW] = v;
             }
         };
-        // a round's new right-image records are fetched at its start and filed at its end: a whole round hides the load
-        auto stage_fetch = [&](int t, uint2 &v) -> int {   // returns the record index, or INT_MIN when this thread has none
-            const int i = rec_hi(t) + 1 + sc;
-            if (sq >= RIN || i > rec_hi(t + 1)) return INT_MIN;
-            v = recR[(size_t)srow * g.W + min(max(i, 0), g.W - 1)];
-            return i;
+        // a round's new records (right image: the KR columns the window advances by; left image: the KR columns the NEXT round
+        // evaluates) are fetched at its start and filed at its end: a whole round hides the loads
+        uint2 sv[NST];
+        auto stage_fetch = [&](int t) {                  // t = -1: during the prologue
+#pragma unroll
+            for (int e = 0; e < NST; e++) {
+                const int u = u0 + e * NPROD * 64;
+                sv[e] = make_uint2(0, 0);
+                if (u < RIN * KR) {
+                    const int q = u / KR, i = rec_hi(t) + 1 + u % KR;
+                    if (i <= rec_hi(t + 1)) sv[e] = recR[(size_t)row_of(q) * g.W + min(max(i, 0), g.W - 1)];
+                } else if (u < NITEM) {
+                    const int v2 = u - RIN * KR;
+                    sv[e] = get_left(v2 / KR, KR * (t + 2) + SH2 + v2 % KR);
+                }
+            }
         };
-        uint2 sv = make_uint2(0, 0);
-        int si = stage_fetch(-1, sv);
+        auto stage_file = [&](int t) {
+#pragma unroll
+            for (int e = 0; e < NST; e++) {
+                const int u = u0 + e * NPROD * 64;
+                if (u < RIN * KR) {
+                    const int q = u / KR, i = rec_hi(t) + 1 + u % KR;
+                    if (i <= rec_hi(t + 1)) put_rec(q, i, sv[e]);
+                } else if (u < NITEM) {
+                    const int v2 = u - RIN * KR;
+                    put_left(v2 / KR, KR * (t + 2) + SH2 + v2 % KR, sv[e]);
+                }
+            }
+        };
+        stage_fetch(-1);
         // prologue: everything round 0 reads: xv in [-SH2 - 1, KR + SH2) (the slot at -SH2 - 1 is only ever subtracted at x = 0,
         // where the chain does not slide; it is produced anyway so that no slot is read before it was written)
-        for (int xv = -SH2 - 1 + p; xv < KR + SH2; xv += NPROD) produce(xv);
-        if (si != INT_MIN) put_rec(sq, si, sv);
+        {
+            Col c;
+            for (int xv = -SH2 - 1 + p; xv < KR + SH2; xv += NPROD) { load_col(xv, c); compute_col(c); }
+        }
+        stage_file(-1);
         __syncthreads();
         for (int t = 0; t < nr; t++) {
             const int x0 = KR * (t + 1) + SH2;           // what round t + 1 needs beyond what round t had
-            si = stage_fetch(t, sv);
-            if (t + 1 < nr)
-                for (int c = p; c < KR; c += NPROD) produce(x0 + c);
-            if (si != INT_MIN) put_rec(sq, si, sv);
+            stage_fetch(t);
+            if (t + 1 < nr) {
+                Col ca, cb;
+                load_col(x0 + p, ca);
+#pragma unroll
+                for (int c = 0; c < CPP; c += 2) {
+                    if (c + 1 < CPP) load_col(x0 + p + (c + 1) * NPROD, cb);
+                    compute_col(ca);
+                    if (c + 2 < CPP) load_col(x0 + p + (c + 2) * NPROD, ca);
+                    if (c + 1 < CPP) compute_col(cb);
+                }
+            }
+            stage_file(t);
             __syncthreads();
         }
         return;
@@ -1092,29 +1148,36 @@ __global__ void __launch_bounds__(256) k_cost_fwd(const uint2 *__restrict__ recL
 #pragma unroll
     for (int j = 0; j < NPL; j++) { P[j] = valid ? 0 : PADPK; C[j] = 0; }
     auto ldv = [&](int xv) { return *(const int4 *)&sV[slot_of(xv)][rl][k * NPL]; };
-    __syncthreads();                                      // the producers' prologue (the window staging above was barrier one)
+    __syncthreads();                                      // the producers' prologue (the staging above was barrier one)
     for (int t = 0; t < nr; t++) {
-        const int xe = min(KR * (t + 1), W1);
-        for (int x = KR * t; x < xe; x++) {
-            if (x == 0) {
+        const int xb = KR * t;
+        // the round's V columns [xb - SH2 - 1, xb + KR + SH2) into registers first: the chain below then never waits for LDS
+        int4 v[KR + 2 * SH2 + 1];
 #pragma unroll
-                for (int i = -SH2; i <= SH2; i++) {
-                    const int4 v = ldv(i);
-                    C[0] = pk_add(C[0], v.x); C[1] = pk_add(C[1], v.y); C[2] = pk_add(C[2], v.z); C[3] = pk_add(C[3], v.w);
+        for (int i = 0; i < KR + 2 * SH2 + 1; i++) v[i] = ldv(xb - SH2 - 1 + i);
+#pragma unroll
+        for (int c = 0; c < KR; c++) {
+            const int x = xb + c;
+            if (x < W1) {
+                if (x == 0) {
+#pragma unroll
+                    for (int i = 1; i <= 2 * SH2 + 1; i++) {   // V'(-SH2) .. V'(SH2)
+                        C[0] = pk_add(C[0], v[i].x); C[1] = pk_add(C[1], v[i].y); C[2] = pk_add(C[2], v[i].z); C[3] = pk_add(C[3], v[i].w);
+                    }
+                } else {
+                    const int4 a = v[c + 2 * SH2 + 1], b = v[c];   // V'(x + SH2), V'(x - SH2 - 1)
+                    C[0] = pk_sub(pk_add(C[0], a.x), b.x); C[1] = pk_sub(pk_add(C[1], a.y), b.y);
+                    C[2] = pk_sub(pk_add(C[2], a.z), b.z); C[3] = pk_sub(pk_add(C[3], a.w), b.w);
                 }
-            } else {
-                const int4 a = ldv(x + SH2), b = ldv(x - SH2 - 1);
-                C[0] = pk_sub(pk_add(C[0], a.x), b.x); C[1] = pk_sub(pk_add(C[1], a.y), b.y);
-                C[2] = pk_sub(pk_add(C[2], a.z), b.z); C[3] = pk_sub(pk_add(C[3], a.w), b.w);
+                if (row_ok) *(int4 *)(crow + (size_t)x * DPW) = make_int4(C[0], C[1], C[2], C[3]);
+                if ((x & (K - 1)) == 0 && x / K < nfull) {   // the state entering segment x / K (k_hscan2's checkpoint layout)
+                    const int sidx = x / K;
+                    *(int4 *)(ck + (size_t)sidx * CKS) = make_int4(P[0], P[1], P[2], P[3]);
+                    if (first) ckrow[(size_t)sidx * CKS + DPW] = minp;
+                }
+                sgm_step_g<NPL, LPC, PADDED>(P, minp, C, P1pk, g.P2, first, last, valid);
+                if (x >= nfull * K && row_ok) *(int4 *)(hrow + (size_t)x * DPW) = make_int4(P[0], P[1], P[2], P[3]);   // tail: L_left parked
             }
-            if (row_ok) *(int4 *)(crow + (size_t)x * DPW) = make_int4(C[0], C[1], C[2], C[3]);
-            if ((x & (K - 1)) == 0 && x / K < nfull) {   // the state entering segment x / K (k_hscan2's checkpoint layout)
-                const int sidx = x / K;
-                *(int4 *)(ck + (size_t)sidx * CKS) = make_int4(P[0], P[1], P[2], P[3]);
-                if (first) ckrow[(size_t)sidx * CKS + DPW] = minp;
-            }
-            sgm_step_g<NPL, LPC, PADDED>(P, minp, C, P1pk, g.P2, first, last, valid);
-            if (x >= nfull * K && row_ok) *(int4 *)(hrow + (size_t)x * DPW) = make_int4(P[0], P[1], P[2], P[3]);   // tail: L_left parked
         }
         __syncthreads();
     }
