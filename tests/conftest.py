@@ -7,6 +7,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the recommended setting of INTEGRATION.md for processes that use the batch entry points; the test run is such an application
+# (the package itself never edits the environment)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def pytest_configure(config):
