@@ -2515,14 +2515,20 @@ __host__ __device__ void umeyama_from_sums(const double *s /*ICP slots*/, double
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) { StS[i][j] = 0; for (int k = 0; k < 3; k++) StS[i][j] += sigma[k][i] * sigma[k][j]; }
     jacobi_eig3(StS, V);
-    int ord[3] = {0, 1, 2};   // eigenvalues in descending order (insertion sort of three)
-    for (int a = 1; a < 3; a++)
-        for (int b = a; b > 0 && StS[ord[b]][ord[b]] > StS[ord[b - 1]][ord[b - 1]]; b--) { const int t = ord[b]; ord[b] = ord[b - 1]; ord[b - 1] = t; }
+    // eigenvalues in descending order, eigenvectors with them: the stable insertion sort of three as its compare-and-swap network
+    // (0,1) (1,2) (0,1) on VALUES -- an index permutation (V[r][ord[c]]) is a dynamically indexed local array, which the compiler
+    // keeps in scratch memory: several dependent memory round trips in the one thread the whole loop waits for
+    double ev[3] = {StS[0][0], StS[1][1], StS[2][2]};
     double Vs[3][3], Us[3][3], sv[3];
-    for (int c = 0; c < 3; c++) {
-        for (int r = 0; r < 3; r++) Vs[r][c] = V[r][ord[c]];
-        sv[c] = sqrt(fmax(StS[ord[c]][ord[c]], 0.0));
-    }
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Vs[r][c] = V[r][c];
+    auto cswap = [&](int a, int b) {   // a < b: swap when the later one is strictly larger (ties keep their order)
+        if (ev[b] > ev[a]) {
+            const double t = ev[a]; ev[a] = ev[b]; ev[b] = t;
+            for (int r = 0; r < 3; r++) { const double u = Vs[r][a]; Vs[r][a] = Vs[r][b]; Vs[r][b] = u; }
+        }
+    };
+    cswap(0, 1); cswap(1, 2); cswap(0, 1);
+    for (int c = 0; c < 3; c++) sv[c] = sqrt(fmax(ev[c], 0.0));
     int rank = 0;   // singular values are in descending order: the deficient columns come last
     for (int c = 0; c < 3; c++) {
         double u[3] = {0, 0, 0};
