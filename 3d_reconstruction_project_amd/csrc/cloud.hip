@@ -1282,6 +1282,11 @@ __global__ void __launch_bounds__(256) k_pack_q10(GridView g, int64_t n, unsigne
 
 __device__ __forceinline__ int med3_i32(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
 
+// G: groups of four candidates requested together before any of them is used (1: one gather per step of the scan, the form for
+// large clouds, where three waves per SIMD hide the gathers; 3: for clouds so small that a SIMD holds one wave -- a scanning-loop
+// frame of 40 k points is 160 workgroups on 256 CUs -- and every dependent gather is a full memory round trip: the same candidates
+// in the same order, so the same keys and the same result)
+template <int G>
 __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, double py, double pz, int cx, int cy, int cz, double r2,
                                              double &best, int &bi, int *__restrict__ sRun /* [18][ICP_BLOCK] */) {
     constexpr int B = 256;   // = ICP_BLOCK (declared below)
@@ -1327,9 +1332,7 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
     // four candidates per 16-byte gather; the distance arithmetic runs two candidates per instruction (v_pk_add / v_pk_mul /
     // v_pk_fma_f32: 6 packed instructions per pair instead of 12 scalar ones; lane-wise IEEE, so the keys are unchanged)
     typedef float v2f __attribute__((ext_vector_type(2)));
-    auto scan4 = [&](int j0, int e, float qyr, float qzr) {
-        const uint4_a4 W = *(const uint4_a4 *)(g.q10 + j0);
-        const int rem = e - j0;
+    auto scan4w = [&](const uint4_a4 W, int rem, float qyr, float qzr) {
         int keys[4];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -1353,8 +1356,20 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
         }
         ord += 4;
     };
+    auto scan4 = [&](int j0, int e, float qyr, float qzr) { scan4w(*(const uint4_a4 *)(g.q10 + j0), e - j0, qyr, qzr); };
     // centre row first: it gives the pruning threshold for the other eight
-    for (int j0 = rb[0]; j0 < re[0]; j0 += 4) scan4(j0, re[0], qyc - 1024.5f, qzc - 1024.5f);
+    if (G == 1) {
+        for (int j0 = rb[0]; j0 < re[0]; j0 += 4) scan4(j0, re[0], qyc - 1024.5f, qzc - 1024.5f);
+    } else {
+        for (int j0 = rb[0]; j0 < re[0]; j0 += 4 * G) {
+            uint4_a4 W[G];
+#pragma unroll
+            for (int q = 0; q < G; q++) W[q] = *(const uint4_a4 *)(g.q10 + min(j0 + 4 * q, re[0] - 1));   // clamped: a group past the run is not used
+#pragma unroll
+            for (int q = 0; q < G; q++)
+                if (j0 + 4 * q < re[0]) scan4w(W[q], re[0] - (j0 + 4 * q), qyc - 1024.5f, qzc - 1024.5f);
+        }
+    }
     const float thr = fminf(thr_r, thr_of(__int_as_float(k1 & ~1023)) * 1.0003f);   // (key truncation: the key is below f by < 2^-13)
     const bool trim = de == 3 && xa == x0;         // the run is exactly the cells cx-1, cx, cx+1 (no clamping at the grid border)
     const float sxl = (qxc - 1024.f) * (qxc - 1024.f), sxh = (2048.f - qxc) * (2048.f - qxc);
@@ -1379,20 +1394,43 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
     {
         int k = 1, j0 = 0, e = 0;
         float qyr = 0.f, qzr = 0.f;
-        for (;;) {
-            if (j0 >= e) {
-                if (k >= nr) break;
-                j0 = sRun[(k * 2) * B + tid];
-                const int lr = sRun[(k * 2 + 1) * B + tid];
-                e = j0 + (lr & 0xfffff);
-                const int r = lr >> 20;
-                const int rz = (r * 11) >> 5, ry = r - 3 * rz;
-                qyr = qyc - 0.5f - 1024.f * (float)ry;
-                qzr = qzc - 0.5f - 1024.f * (float)rz;
-                k++;
+        auto next_run = [&]() {     // false: the list is exhausted
+            if (k >= nr) return false;
+            j0 = sRun[(k * 2) * B + tid];
+            const int lr = sRun[(k * 2 + 1) * B + tid];
+            e = j0 + (lr & 0xfffff);
+            const int r = lr >> 20;
+            const int rz = (r * 11) >> 5, ry = r - 3 * rz;
+            qyr = qyc - 0.5f - 1024.f * (float)ry;
+            qzr = qzc - 0.5f - 1024.f * (float)rz;
+            k++;
+            return true;
+        };
+        if (G == 1) {
+            for (;;) {
+                if (j0 >= e && !next_run()) break;
+                scan4(j0, e, qyr, qzr);
+                j0 += 4;
             }
-            scan4(j0, e, qyr, qzr);
-            j0 += 4;
+        } else {
+            // walk the list G groups ahead (addresses and row constants only), request them all, then use them in the same order
+            for (bool more = true; more;) {
+                int aj[G], ar[G];
+                float ay[G], az[G];
+                int ng = 0;
+#pragma unroll
+                for (int q = 0; q < G; q++) {
+                    aj[q] = 0; ar[q] = 0; ay[q] = 0.f; az[q] = 0.f;
+                    if (more && j0 >= e) more = next_run();
+                    if (more) { aj[q] = j0; ar[q] = e - j0; ay[q] = qyr; az[q] = qzr; j0 += 4; ng = q + 1; }
+                }
+                uint4_a4 W[G];
+#pragma unroll
+                for (int q = 0; q < G; q++) W[q] = *(const uint4_a4 *)(g.q10 + aj[q]);     // unused slots read entry 0
+#pragma unroll
+                for (int q = 0; q < G; q++)
+                    if (q < ng) scan4w(W[q], ar[q], ay[q], az[q]);
+            }
         }
     }
     if (k1 == KINF) return;                        // nothing scanned: the caller goes on to the outer shells
@@ -1560,14 +1598,14 @@ __device__ __forceinline__ void icp_accumulate(const GridView &g, const double *
     
 }
 
-enum { SEARCH_EXACT = 0, SEARCH_F32 = 1, SEARCH_Q10 = 2 };
+enum { SEARCH_EXACT = 0, SEARCH_F32 = 1, SEARCH_Q10 = 2, SEARCH_Q10_DEEP = 3 /* nn_block_q10<3>: small clouds */ };
 template <int MODE, int SEARCH>
-__global__ void __launch_bounds__(ICP_BLOCK, 3) k_icp_eval(GridView g, const double *__restrict__ src, const double *__restrict__ src_n,
+__global__ void __launch_bounds__(ICP_BLOCK, SEARCH == SEARCH_Q10_DEEP ? 2 : 3) k_icp_eval(GridView g, const double *__restrict__ src, const double *__restrict__ src_n,
                                                         const double *__restrict__ tgt_n /* cell-sorted order */, int64_t ns,
                                                         const IcpState *__restrict__ st, double max_dist, double eps, double *__restrict__ partial,
                                                         int *__restrict__ corr /* optional [ns] target original index or -1 */) {
     static_assert(ICP_BLOCK == 256, "nn_block_q10 assumes 256 threads");
-    __shared__ int sRun[SEARCH == SEARCH_Q10 ? 18 * ICP_BLOCK : 1];
+    __shared__ int sRun[SEARCH >= SEARCH_Q10 ? 18 * ICP_BLOCK : 1];
     if (st->done) return;                        // the loop ended in an earlier launch of this batch (uniform)
     const Rigid T = load_rigid(st);
     double acc[ICP_SLOTS];
@@ -1597,7 +1635,8 @@ __global__ void __launch_bounds__(ICP_BLOCK, 3) k_icp_eval(GridView g, const dou
         double best = r2;
         int bi = -1;
         if (!icp_out_of_reach(g, cx, cy, cz)) {
-            if (SEARCH == SEARCH_Q10) nn_block_q10(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun);
+            if (SEARCH == SEARCH_Q10_DEEP) nn_block_q10<3>(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun);
+            else if (SEARCH == SEARCH_Q10) nn_block_q10<1>(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun);
             else if (SEARCH == SEARCH_F32) nn_block_top4(g, px, py, pz, cx, cy, cz, best, bi);
             else nn_block_global(g, px, py, pz, cx, cy, cz, best, bi);
             nn_outer_shells(g, px, py, pz, cx, cy, cz, smax, best, bi);
@@ -1628,7 +1667,7 @@ __global__ void __launch_bounds__(ICP_BLOCK, 3) k_icp_eval(GridView g, const dou
 template <int SEARCH>
 __global__ void __launch_bounds__(ICP_BLOCK, 4) k_icp_search(GridView g, const double *__restrict__ src, int64_t ns, const IcpState *__restrict__ st,
                                                              double max_dist, int *__restrict__ nn) {
-    __shared__ int sRun[SEARCH == SEARCH_Q10 ? 18 * ICP_BLOCK : 1];
+    __shared__ int sRun[SEARCH >= SEARCH_Q10 ? 18 * ICP_BLOCK : 1];
     if (st->done) return;
     const Rigid T = load_rigid(st);
     const double r2 = max_dist * max_dist;
@@ -1652,7 +1691,8 @@ __global__ void __launch_bounds__(ICP_BLOCK, 4) k_icp_search(GridView g, const d
         double best = r2;
         int bi = -1;
         if (!icp_out_of_reach(g, cx, cy, cz)) {
-            if (SEARCH == SEARCH_Q10) nn_block_q10(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun);
+            if (SEARCH == SEARCH_Q10_DEEP) nn_block_q10<3>(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun);
+            else if (SEARCH == SEARCH_Q10) nn_block_q10<1>(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun);
             else if (SEARCH == SEARCH_F32) nn_block_top4(g, px, py, pz, cx, cy, cz, best, bi);
             else nn_block_global(g, px, py, pz, cx, cy, cz, best, bi);
             nn_outer_shells(g, px, py, pz, cx, cy, cz, smax, best, bi);
@@ -3032,6 +3072,10 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
                                    : (int)std::min<int64_t>((ns + ICP_BLOCK - 1) / ICP_BLOCK, (int64_t)std::max(cus, 1) * 3);
     double *d_part = (double *)ar.get((size_t)nblocks * ICP_SLOTS * 8);
     IcpState *d_st = (IcpState *)ar.get(sizeof(IcpState));
+    // small source clouds (at most two workgroups per CU: every gather of the scan is a full round trip) take the search form
+    // that keeps three candidate groups in flight; R3D_ICP_DEEP=0 / 1 forces either form (A/B)
+    static const int deep_env = [] { const char *e = getenv("R3D_ICP_DEEP"); return !e ? -1 : atoi(e) != 0; }();
+    const bool deep_search = deep_env >= 0 ? deep_env == 1 : ns <= (int64_t)ICP_BLOCK * std::max(cus, 1) * 2;
     // R3D_ICP_SPLIT=1: search and accumulation as two kernels (A/B; same partial sums bit for bit)
     static const bool split_env = [] { const char *e = getenv("R3D_ICP_SPLIT"); return e && !strcmp(e, "1"); }();
     const bool split_impl = split_env && !tiled_impl;
@@ -3079,7 +3123,8 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
                     default: k_icp_accum<MODE_GICP><<<nblocks, ICP_BLOCK, 0, ctx->stream>>>(G.v, d_s, d_sn, d_tns, ns, d_st, eps, d_nn, d_part); break;
                 }
             } else
-            if (G.v.q10) { R3D_ICP_MODES(SEARCH_Q10) }
+            if (G.v.q10 && deep_search) { R3D_ICP_MODES(SEARCH_Q10_DEEP) }
+            else if (G.v.q10) { R3D_ICP_MODES(SEARCH_Q10) }
             else if (G.v.fx) { R3D_ICP_MODES(SEARCH_F32) }
             else { R3D_ICP_MODES(SEARCH_EXACT) }
 #undef R3D_ICP_MODES
