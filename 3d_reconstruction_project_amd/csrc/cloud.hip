@@ -2944,6 +2944,9 @@ int voxel_segments(r3d_ctx *ctx, DevArena &ar, const double *d_p, int64_t n, dou
         }
         V.nseg = (int64_t)last_scan + last_flag;
         if (df.ok()) return R3D_OK;
+        static const bool dbg = [] { const char *e = getenv("R3D_SORT_DEBUG"); return e && *e == '1'; }();
+        if (dbg) fprintf(stderr, "[r3d sort] voxel grid: deferred test failed (n=%lld runs=%d max_runs_per_bucket=%d): sorting again with the radix sort\n",
+                         (long long)n, (int)(df.h_total >> 32), df.h_maxruns);
     }
     return r3d_fail(ctx, R3D_E_HIP, "voxel grid: the fallback sort did not complete");
 }

@@ -680,6 +680,23 @@ def test_counting_sort_is_the_stable_key_index_order(r3d, case):
         np.testing.assert_array_equal(keys.astype(np.int64), want_keys[want])
 
 
+def test_voxel_grid_survives_the_deferred_sort_test_failing(r3d):
+    """Round 4: the voxel grid defers its sort's fallback test into the read-back of the segment count (one host round trip less).
+    More than 4 096 single-point runs in ONE bucket make that test fail AFTER the counting sort's kernels were enqueued (they must
+    have guarded themselves: `k_cs_rank` / `k_cs_emit` read the test on the device); the grid then sorts again with the library
+    radix sort and must still be the oracle's, bit for bit -- and a well-behaved cloud right afterwards as well (same arena)."""
+    pts = np.tile([-1.0 + 0.005, -2.0 + 0.005, 0.5], (42_000, 1))
+    pts[:, 2] += 0.01 * (np.arange(42_000) % 7) + 0.005            # seven voxels of one column, visited in turn: 6 000 runs per voxel
+    col = np.random.default_rng(1).random(pts.shape)
+    got = r3d.cloud_ops.voxel_down_sample(pts, 0.01, col)
+    want = co.voxel_down_sample(pts, 0.01, colors=col)
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
+    assert len(got[0]) == 7
+    ok = np.random.default_rng(2).random((50_000, 3))
+    np.testing.assert_array_equal(r3d.cloud_ops.voxel_down_sample(ok, 0.02)[0], co.voxel_down_sample(ok, 0.02))
+
+
 def test_normals_on_degenerate_neighbourhoods_follow_the_closed_form(r3d):
     """The branches of FastEigen3x3 that scanned surfaces rarely take, kernel against oracle (same formulas, same fused
     multiply-adds): exactly planar lattices (a zero eigenvalue, two equal ones), axis-aligned point sets whose covariance is
