@@ -19,7 +19,7 @@ from oracle import cloud_oracle as co
 synth = importlib.import_module("3d_reconstruction_project_amd.synth")
 n = 0
 for (W, H, D, bs, minD) in [(64, 48, 16, 5, 0), (97, 33, 32, 3, 0), (130, 70, 48, 7, -8), (40, 20, 16, 1, 0), (300, 200, 128, 5, 0),
-                            (17, 9, 16, 5, 0), (200, 64, 256, 9, 0)]:
+                            (17, 9, 16, 5, 0), (200, 64, 256, 9, 0), (60, 12, 16, 5, 0), (50, 24, 16, 11, 0), (33, 2, 16, 5, 0)]:
     L, R, _ = synth.stereo_pair(W, H, max(D, 16), seed=W)
     for spk in (0, 50):
         p = so.make_params(minDisparity=minD, numDisparities=D, blockSize=bs, P1=8 * bs * bs, P2=32 * bs * bs, disp12MaxDiff=1,
