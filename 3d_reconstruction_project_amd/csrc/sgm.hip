@@ -39,6 +39,10 @@ __device__ __forceinline__ int as_i(s16x2 v) { return __builtin_bit_cast(int, v)
 __device__ __forceinline__ int as_i(u16x2 v) { return __builtin_bit_cast(int, v); }
 __device__ __forceinline__ int pk_add(int a, int b) { return as_i(as_s(a) + as_s(b)); }
 __device__ __forceinline__ int pk_sub(int a, int b) { return as_i(as_s(a) - as_s(b)); }
+// Both halves known not to carry / borrow into each other (block costs: at most 121 * 189 = 22 869 per half): ONE 32-bit add, which
+// gfx950 issues in ~2.5 cycles per wave against ~4.4 for v_pk_add_u16 (tools/micro/valu_rate.hip); same bits.
+__device__ __forceinline__ int pk_add_nc(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+__device__ __forceinline__ int pk_sub_nb(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
 __device__ __forceinline__ int pk_add_sat(int a, int b) { return as_i(__builtin_elementwise_add_sat(as_s(a), as_s(b))); }
 __device__ __forceinline__ int pk_min(int a, int b) { return as_i(__builtin_elementwise_min(as_s(a), as_s(b))); }
 __device__ __forceinline__ int pk_umax(int a, int b) { return as_i(__builtin_elementwise_max(as_u(a), as_u(b))); }
@@ -545,11 +549,16 @@ __global__ void __launch_bounds__(NWAVE * 64) k_cost2(const uint2 *__restrict__ 
 #pragma unroll
         for (int j = 0; j < NPL; j++) {
             const int rj = ri0 - 2 * j;
-            const int2 *p = (const int2 *)&sW[b][rj * 6 + (rj >> 4) * 8];
-            const int2 a = p[0], bq = p[1], c = p[2];      // (Vg, Vg0) (Vg1, Vi) (Vi0, Vi1)
+            // three ds_read_b64 (banks mod 64, 2 LDS cycles each, conflict-free with the padding above).  Volatile keeps the compiler
+            // from pairing two of them into ds_read2_b64, which is banked mod 32 in 16-lane groups: chunks k and k+4 then collide
+            // (2-way) and the pair costs 16 LDS cycles instead of 4 -- the 31 % bank conflicts of the round-2/3 counters.
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            typedef const volatile __attribute__((address_space(3))) v2i lds_v2i;   // (a plain volatile pointer would read through flat_load)
+            lds_v2i *p = (lds_v2i *)&sW[b][rj * 6 + (rj >> 4) * 8];
+            const v2i a = p[0], bq = p[1], c = p[2];       // (Vg, Vg0) (Vg1, Vi) (Vi0, Vi1)
             const int cg = bt_cost_pk(Ug, Ug0, Ug1, a.x, a.y, bq.x);
             const int ci = bt_cost_pk(Ui, Ui0, Ui1, bq.y, c.x, c.y);
-            pix[j] = pk_add(cg, (ci >> 2) & 0x3fff3fff);
+            pix[j] = pk_add_nc(cg, (ci >> 2) & 0x3fff3fff);
         }
     };
 
@@ -581,8 +590,8 @@ __global__ void __launch_bounds__(NWAVE * 64) k_cost2(const uint2 *__restrict__ 
 #pragma unroll
         for (int j = 0; j < NPL / 2; j++) {
             const int old = ring[0][j];
-            vs[2 * j] = pk_add(pk_sub(vs[2 * j], __builtin_amdgcn_perm(old, old, 0x0c010c00)), pn[2 * j]);
-            vs[2 * j + 1] = pk_add(pk_sub(vs[2 * j + 1], __builtin_amdgcn_perm(old, old, 0x0c030c02)), pn[2 * j + 1]);
+            vs[2 * j] = pk_add_nc(pk_sub_nb(vs[2 * j], __builtin_amdgcn_perm(old, old, 0x0c010c00)), pn[2 * j]);
+            vs[2 * j + 1] = pk_add_nc(pk_sub_nb(vs[2 * j + 1], __builtin_amdgcn_perm(old, old, 0x0c030c02)), pn[2 * j + 1]);
         }
 #pragma unroll
         for (int q = 0; q + 1 < R; q++)
@@ -609,8 +618,8 @@ __global__ void __launch_bounds__(NWAVE * 64) k_cost2(const uint2 *__restrict__ 
                 const int col = min(max(tile_x0 + cl + i, 0), g.W1 - 1) - tile_x0;
                 const int4 v0 = *(const int4 *)&sV[b][col * DPW + (DPW / 2) * (col & 1) + 4 * k];
                 const int4 v1 = *(const int4 *)&sV[b][col * DPW + (DPW / 2) * ((col & 1) ^ 1) + 4 * k];
-                c[0] = pk_add(c[0], v0.x); c[1] = pk_add(c[1], v0.y); c[2] = pk_add(c[2], v0.z); c[3] = pk_add(c[3], v0.w);
-                c[4] = pk_add(c[4], v1.x); c[5] = pk_add(c[5], v1.y); c[6] = pk_add(c[6], v1.z); c[7] = pk_add(c[7], v1.w);
+                c[0] = pk_add_nc(c[0], v0.x); c[1] = pk_add_nc(c[1], v0.y); c[2] = pk_add_nc(c[2], v0.z); c[3] = pk_add_nc(c[3], v0.w);
+                c[4] = pk_add_nc(c[4], v1.x); c[5] = pk_add_nc(c[5], v1.y); c[6] = pk_add_nc(c[6], v1.z); c[7] = pk_add_nc(c[7], v1.w);
             }
             if (VCH) {
                 sgm_step_g<NPL, LPC, true>(LT, ltmin, c, P1pk, g.P2, k == 0, k == LPC - 1, lane_valid);
@@ -1755,8 +1764,10 @@ __global__ void __launch_bounds__(NWAVE * 64) k_vscan3(const uint2 *__restrict__
 #pragma unroll
         for (int j = 0; j < NPL; j++) {
             const int rj = ri0 - 2 * j;
-            const int2 *p = (const int2 *)&sW[b][rj * 6 + (rj >> 4) * 8];
-            const int2 aa = p[0], bq = p[1], c = p[2];
+            typedef int v2i __attribute__((ext_vector_type(2)));           // three ds_read_b64, never ds_read2_b64: see k_cost2
+            typedef const volatile __attribute__((address_space(3))) v2i lds_v2i;
+            lds_v2i *p = (lds_v2i *)&sW[b][rj * 6 + (rj >> 4) * 8];
+            const v2i aa = p[0], bq = p[1], c = p[2];
             const int cg = bt_cost_pk(Ug, Ug0, Ug1, aa.x, aa.y, bq.x);
             const int ci = bt_cost_pk(Ui, Ui0, Ui1, bq.y, c.x, c.y);
             pix[j] = pk_add(cg, (ci >> 2) & 0x3fff3fff);

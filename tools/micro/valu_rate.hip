@@ -1,4 +1,4 @@
-// Issue rate of the vector instructions the SGM kernels are made of, per SIMD, at 1 / 2 / 4 waves per SIMD (gfx950); inline
+// Issue rate of the vector instructions the SGM and registration kernels are made of, per SIMD, at 1 / 2 / 4 waves per SIMD (gfx950); inline
 // assembly, 16 independent registers, so nothing is folded away.
 // Build + run: hipcc --offload-arch=gfx950 -O3 tools/micro/valu_rate.hip -o tools/micro/bin/valu_rate && tools/micro/bin/valu_rate
 #include <hip/hip_runtime.h>
@@ -10,6 +10,11 @@ __global__ void __launch_bounds__(64) k(int *out, int iters, int seed) {
 #pragma unroll
     for (int i = 0; i < 16; i++) a[i] = seed * (i + 1) + threadIdx.x;
     int b = seed | 1;
+    double p[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) p[i] = (OP == 20 || (OP >= 31 && OP <= 35) || OP == 45) ? 1.0 + seed * (i + 1) + threadIdx.x : 0.0;
+    double pb = 1.0 + 1e-9 * seed;
+    const unsigned long long m = 0x5555555555555555ull * (unsigned)seed;
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -27,14 +32,50 @@ __global__ void __launch_bounds__(64) k(int *out, int iters, int seed) {
     else if (OP == 10) asm volatile("v_pk_lshrrev_b16 %0, 2, %0" : "+v"(a[i]));                                         \
     else if (OP == 11) asm volatile("v_min_i32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b)); \
     else if (OP == 12) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b));                             \
-    else if (OP == 13) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(b));
+    else if (OP == 13) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(b));                                          \
+    else if (OP == 14) asm volatile("v_med3_i32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(seed));                      \
+    else if (OP == 15) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                      \
+    else if (OP == 16) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                      \
+    else if (OP == 17) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                      \
+    else if (OP == 18) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(seed));                      \
+    else if (OP == 19) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(seed));                       \
+    else if (OP == 20) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pb), "v"(pb));                     \
+    else if (OP == 21) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a[i]));                                               \
+    else if (OP == 22) asm volatile("v_bfe_u32 %0, %0, 12, 10" : "+v"(a[i]));                                           \
+    else if (OP == 23) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(seed));                    \
+    else if (OP == 24) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                      \
+    else if (OP == 25) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(a[i]));                                            \
+    else if (OP == 26) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                      \
+    else if (OP == 27) asm volatile("v_max_i32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                      \
+    else if (OP == 28) asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(seed));                      \
+    else if (OP == 29) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                   \
+    else if (OP == 30) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(seed));                   \
+    else if (OP == 31) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pb), "v"(pb));                        \
+    else if (OP == 32) asm volatile("v_add_f64 %0, %0, %1" : "+v"(p[i]) : "v"(pb));                                     \
+    else if (OP == 33) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(p[i]) : "v"(pb));                                     \
+    else if (OP == 34) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pb));                                  \
+    else if (OP == 35) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pb));                                  \
+    else if (OP == 36) asm volatile("v_cmp_lt_i32 vcc, %1, %2\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b), "v"(seed) : "vcc"); \
+    else if (OP == 37) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "s"(m));                      \
+    else if (OP == 38) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                       \
+    else if (OP == 39) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(a[i]) : "v"(b));                               \
+    else if (OP == 40) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(seed));                      \
+    else if (OP == 41) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                      \
+    else if (OP == 42) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                      \
+    else if (OP == 43) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                      \
+    else if (OP == 44) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(seed));                      \
+    else if (OP == 45) asm volatile("v_cvt_f64_f32 %0, %1" : "+v"(p[i]) : "v"(b));                                      \
+    else if (OP == 46) asm volatile("v_sad_u8 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(seed));                        \
+    else if (OP == 47) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a[i]));                                            \
+    else if (OP == 48) asm volatile("v_ashrrev_i32 %0, 3, %0" : "+v"(a[i]));                                            \
+    else if (OP == 49) asm volatile("v_pk_mad_i16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(seed));
             REP16(ONE)
 #undef ONE
         }
     }
     int s = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) s ^= a[i];
+    for (int i = 0; i < 16; i++) s ^= a[i] ^ (int)p[i];
     if (s == 0x12345) out[0] = s;
 }
 template <int OP>
@@ -54,6 +95,13 @@ void run(const char *name) {
 int main() {
     run<0>("v_add_u32"); run<1>("v_pk_add_i16"); run<2>("v_pk_min_i16"); run<7>("v_pk_sub_u16 clamp"); run<8>("v_pk_max_u16");
     run<10>("v_pk_lshrrev_b16"); run<3>("v_perm_b32"); run<4>("v_alignbit_b32"); run<9>("v_and_b32"); run<6>("v_min_i32");
-    run<12>("v_cndmask_b32"); run<13>("v_mov_b32"); run<5>("v_mov_b32_dpp"); run<11>("v_min_i32_dpp");
+    run<13>("v_mov_b32"); run<5>("v_mov_b32_dpp"); run<11>("v_min_i32_dpp");
+    run<36>("v_cmp+v_cndmask (2)"); run<37>("v_cndmask sgpr mask"); run<14>("v_med3_i32"); run<15>("v_min_u32"); run<27>("v_max_i32"); run<28>("v_min3_i32");
+    run<16>("v_min_f32"); run<17>("v_max_f32"); run<18>("v_med3_f32"); run<44>("v_max3_f32"); run<19>("v_fma_f32"); run<20>("v_pk_fma_f32");
+    run<34>("v_pk_mul_f32"); run<35>("v_pk_add_f32"); run<21>("v_cvt_f32_u32"); run<22>("v_bfe_u32"); run<23>("v_and_or_b32");
+    run<24>("v_sub_f32"); run<43>("v_add_f32"); run<26>("v_mul_f32"); run<25>("v_lshrrev_b32"); run<47>("v_lshlrev_b32"); run<48>("v_ashrrev_i32");
+    run<38>("v_or_b32"); run<41>("v_xor_b32"); run<42>("v_sub_u32"); run<39>("v_lshl_or_b32"); run<40>("v_add3_u32");
+    run<29>("v_mul_lo_u32"); run<30>("v_mad_u32_u24"); run<46>("v_sad_u8"); run<49>("v_pk_mad_i16");
+    run<31>("v_fma_f64"); run<32>("v_add_f64"); run<33>("v_mul_f64"); run<45>("v_cvt_f64_f32");
     return 0;
 }
