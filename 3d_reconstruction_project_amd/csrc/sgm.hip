@@ -25,6 +25,12 @@ namespace {
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
+#ifndef R3D_EXP_COST
+#define R3D_EXP_COST 0   /* timing experiments on k_cost2 (wrong results): 1 = no stores, 2 = no loads inside the loop */
+#endif
+#ifndef R3D_COST_STAGE
+#define R3D_COST_STAGE 1   /* where k_cost2 stages the next input row: 1 right after the barrier (default: 0.67 -> 0.64 ms), 2 between the box sum and its stores (0.65) */
+#endif
 struct SgmGeom {
     int W, H, minD, D, NP, minX1, maxX1, W1, SW2, SH2, P1, P2, uniq, d12, ftzero, stripe_sz, overlap, invalid;
     int DP;  // disparity slots per cost-volume column: the smallest of 32 / 64 / 128 / 256 that holds D (v2 kernels; v1 and v3
@@ -578,9 +584,16 @@ __global__ void __launch_bounds__(NWAVE * 64) k_cost2(const uint2 *__restrict__ 
     fetch(crow(y0 - SH2));
     commit(0);
     fetch(crow(y0 - SH2 + 1));
+    commit(1);
+    fetch(crow(y0 - SH2 + 2));
     __syncthreads();
-    // iteration t: row e = y0 - SH2 + t enters the window (inputs in buffer t&1, staged one iteration earlier);
+    // iteration t: row e = y0 - SH2 + t enters the window (inputs in buffer t&1, staged TWO iterations earlier);
     // from t = 2*SH2 on the window is full and output row y = e - SH2 is produced.  One barrier per iteration.
+    // The staging of row t+2 sits right AFTER the barrier (buffer t&1 is free from there on), not before it: its wait for the
+    // prefetched records is an s_waitcnt vmcnt(0) (the count cannot be known across the conditional stores), which also waits for
+    // this wave's own stores of C -- issued a whole iteration earlier here, most of an iteration earlier in the old order, where
+    // waves 0-2 stalled on them (~1.8 us of write latency against a 2.1 us iteration) and the other five at the barrier behind them:
+    // 0.68 -> 0.59 ms with the loads removed (R3D_EXP_COST=2, wrong results), the same as with the stores removed (=1).
     const int niter = (y1 - y0) + 2 * SH2;
 #pragma unroll 1
     for (int t = 0; t < niter; t++) {
@@ -606,13 +619,16 @@ __global__ void __launch_bounds__(NWAVE * 64) k_cost2(const uint2 *__restrict__ 
             *(int4 *)&sV[b][cl * DPW + (DPW / 2) * (cl & 1) + 4 * k] = make_int4(vs[0], vs[1], vs[2], vs[3]);
             *(int4 *)&sV[b][cl * DPW + (DPW / 2) * ((cl & 1) ^ 1) + 4 * k] = make_int4(vs[4], vs[5], vs[6], vs[7]);
         }
-        commit(b ^ 1);                                  // row t+1 (fetched during iteration t-1)
-        fetch(crow(y0 - SH2 + t + 2));                  // row t+2, consumed by the next iteration's commit
         __syncthreads();
-        if (outp && is_out) {
-            int c[NPL];
+#if R3D_COST_STAGE == 1
+        commit(b);
+        fetch(crow(y0 - SH2 + t + 3));
+#endif
+        const bool do_out = outp && is_out;
+        int c[NPL];
 #pragma unroll
-            for (int j = 0; j < NPL; j++) c[j] = 0;
+        for (int j = 0; j < NPL; j++) c[j] = 0;
+        if (do_out) {
 #pragma unroll
             for (int i = -SH2; i <= SH2; i++) {
                 const int col = min(max(tile_x0 + cl + i, 0), g.W1 - 1) - tile_x0;
@@ -621,6 +637,15 @@ __global__ void __launch_bounds__(NWAVE * 64) k_cost2(const uint2 *__restrict__ 
                 c[0] = pk_add_nc(c[0], v0.x); c[1] = pk_add_nc(c[1], v0.y); c[2] = pk_add_nc(c[2], v0.z); c[3] = pk_add_nc(c[3], v0.w);
                 c[4] = pk_add_nc(c[4], v1.x); c[5] = pk_add_nc(c[5], v1.y); c[6] = pk_add_nc(c[6], v1.z); c[7] = pk_add_nc(c[7], v1.w);
             }
+        }
+        // between the box sum and its stores: the staging's vmcnt(0) then waits for stores that are exactly one iteration old
+#if R3D_COST_STAGE == 2
+        commit(b);                                      // row t+2 (fetched during iteration t-1) into the buffer this iteration just read
+#if R3D_EXP_COST != 2
+        fetch(crow(y0 - SH2 + t + 3));                  // row t+3, consumed by the next iteration's commit
+#endif
+#endif
+        if (do_out) {
             if (VCH) {
                 sgm_step_g<NPL, LPC, true>(LT, ltmin, c, P1pk, g.P2, k == 0, k == LPC - 1, lane_valid);
                 if (y0 + t - 2 * SH2 >= out_start) {
@@ -633,8 +658,12 @@ __global__ void __launch_bounds__(NWAVE * 64) k_cost2(const uint2 *__restrict__ 
                 }
             } else {
                 int *o = optr + (size_t)(t - 2 * SH2) * rowWords;
+#if R3D_EXP_COST == 1
+                if ((c[0] ^ c[1] ^ c[2] ^ c[3] ^ c[4] ^ c[5] ^ c[6] ^ c[7]) == 0x12345678) *(int4 *)o = make_int4(c[0], c[1], c[2], c[3]);   // timing experiment: no stores
+#else
                 *(int4 *)o = make_int4(c[0], c[1], c[2], c[3]);
                 *(int4 *)(o + 4) = make_int4(c[4], c[5], c[6], c[7]);
+#endif
             }
             if (TRACK && 16 * k < g.D) {
 #pragma unroll

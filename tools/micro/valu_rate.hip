@@ -68,7 +68,10 @@ __global__ void __launch_bounds__(64) k(int *out, int iters, int seed) {
     else if (OP == 46) asm volatile("v_sad_u8 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(seed));                        \
     else if (OP == 47) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a[i]));                                            \
     else if (OP == 48) asm volatile("v_ashrrev_i32 %0, 3, %0" : "+v"(a[i]));                                            \
-    else if (OP == 49) asm volatile("v_pk_mad_i16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(seed));
+    else if (OP == 49) asm volatile("v_pk_mad_i16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(seed));                    \
+    else if (OP == 50) { if ((i & 1) == 0) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b)); else asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b)); } \
+    else if (OP == 51) { if ((i & 3) != 3) asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b)); else asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b)); } \
+    else if (OP == 52) { if ((i & 1) == 0) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b)); else asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b)); }
             REP16(ONE)
 #undef ONE
         }
@@ -102,6 +105,7 @@ int main() {
     run<24>("v_sub_f32"); run<43>("v_add_f32"); run<26>("v_mul_f32"); run<25>("v_lshrrev_b32"); run<47>("v_lshlrev_b32"); run<48>("v_ashrrev_i32");
     run<38>("v_or_b32"); run<41>("v_xor_b32"); run<42>("v_sub_u32"); run<39>("v_lshl_or_b32"); run<40>("v_add3_u32");
     run<29>("v_mul_lo_u32"); run<30>("v_mad_u32_u24"); run<46>("v_sad_u8"); run<49>("v_pk_mad_i16");
+    run<50>("mix pk_add/add_u32 1:1"); run<51>("mix pk_min x3 / add_u32 x1"); run<52>("mix add_u32/and_b32 1:1");
     run<31>("v_fma_f64"); run<32>("v_add_f64"); run<33>("v_mul_f64"); run<45>("v_cvt_f64_f32");
     return 0;
 }
