@@ -1285,6 +1285,15 @@ __device__ __forceinline__ int med3_i32(int a, int b, int c) { return max(min(a,
 // large clouds, where three waves per SIMD hide the gathers; 3: for clouds so small that a SIMD holds one wave -- a scanning-loop
 // frame of 40 k points is 160 workgroups on 256 CUs -- and every dependent gather is a full memory round trip: the same candidates
 // in the same order, so the same keys and the same result)
+#ifdef R3D_ICP_STATS   // diagnostic build only (csrc/build.sh -DR3D_ICP_STATS, tools/gpu_icp_stats.py): trip counts of the packed search per
+                       // wave, as the maximum over lanes (what the wave executes) and the sum over lanes (what its lanes need)
+__device__ unsigned long long g_icp_stats[16];
+__device__ __forceinline__ void icp_stat(int slot, int v) {
+    int m = v, sum = v;
+    for (int o = 32; o > 0; o >>= 1) { m = max(m, __shfl_xor(m, o)); sum += __shfl_xor(sum, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&g_icp_stats[slot], (unsigned long long)m); atomicAdd(&g_icp_stats[slot + 1], (unsigned long long)sum); }
+}
+#endif
 template <int G>
 __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, double py, double pz, int cx, int cy, int cz, double r2,
                                              double &best, int &bi, int *__restrict__ sRun /* [18][ICP_BLOCK] */) {
@@ -1360,6 +1369,16 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
     };
     auto scan4 = [&](int j0, int e, float qyr, float qzr) { scan4w(*(const uint4_a4 *)(g.q10 + j0), e - j0, qyr, qzr); };
     // centre row first: it gives the pruning threshold for the other eight
+#ifdef R3D_ICP_STATS
+    {
+        int lg = 0, lc = 0;
+        for (int q = 1; q < 9; q++) { lg += (re[q] - rb[q] + 3) >> 2; lc += re[q] - rb[q]; }
+        icp_stat(0, (re[0] - rb[0] + 3) >> 2);      // centre-row groups
+        icp_stat(2, re[0] - rb[0]);                 // centre-row candidates
+        icp_stat(4, lg);                            // groups of the other eight rows before pruning
+        icp_stat(6, lc);
+    }
+#endif
     if (G == 1) {
         for (int j0 = rb[0]; j0 < re[0]; j0 += 4) scan4(j0, re[0], qyc - 1024.5f, qzc - 1024.5f);
     } else {
@@ -1393,6 +1412,16 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
             nr++;
         }
     }
+#ifdef R3D_ICP_STATS
+    {
+        int lg = 0, lc = 0;
+        for (int k = 1; k < nr; k++) { const int len = sRun[(k * 2 + 1) * B + tid] & 0xfffff; lg += (len + 3) >> 2; lc += len; }
+        icp_stat(8, lg);                            // groups of the surviving rows (after the slab test and the end-cell trim)
+        icp_stat(10, lc);
+        icp_stat(12, nr - 1);                       // surviving rows
+        icp_stat(14, 1);                            // [14] waves, [15] queries
+    }
+#endif
     {
         int k = 1, j0 = 0, e = 0;
         float qyr = 0.f, qzr = 0.f;
@@ -4287,6 +4316,13 @@ int r3d_transform_blocks_dev(r3d_ctx *ctx, int32_t n_blocks, const double *const
 }  // extern "C"
 
 // diagnostic: the cell sort on its own (tests compare both implementations with a host lexsort)
+#ifdef R3D_ICP_STATS
+extern "C" int r3d_debug_icp_stats(uint64_t *out16, int reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_icp_stats), 16 * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_icp_stats), z, 16 * 8) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 extern "C" int r3d_debug_sort_by_cell(r3d_ctx *ctx, const double *xyz, int64_t n, const double *org3, double cell, const int32_t *dims3, int32_t key_order,
                                       int32_t impl, int32_t *idx_out, uint64_t *keys_out) {
     R3D_ROCTX_RANGE("r3d_debug_sort_by_cell");
