@@ -2669,7 +2669,10 @@ static int sgm_run_impl(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_p
         const bool small = g.DP < 128;
         const bool four = (g.DP == 128 && !rows2) || small;
         const int rpw = four ? 4 : 2, npl = g.DP == 32 ? 1 : g.DP == 64 ? 2 : four ? 4 : 2 * g.NP;
-        const int K = g.DP == 32 ? K32 : g.DP == 64 ? K64 : four ? K1b : (g.NP == 1 ? K1 : K2);
+        // R3D_HSCAN_K=8: 8-column segments for the D <= 128 layout (half the registers of the default 16: two waves fit a SIMD); A/B
+        static const bool k8_env = [] { const char *e = getenv("R3D_HSCAN_K"); return e && !strcmp(e, "8"); }();
+        const bool k8 = k8_env && g.DP == 128 && four;
+        const int K = g.DP == 32 ? K32 : g.DP == 64 ? K64 : four ? (k8 ? 8 : K1b) : (g.NP == 1 ? K1 : K2);
         const int nwaves = (h + rpw - 1) / rpw;
         if ((rc = r3d_reserve(ctx, ws.ckpt, (size_t)(h + 8) * (g.W1 / K + 1) * (NPW + 4) * 4))) return rc;   // by image row (k_hscan2)
         const int *cp = (const int *)ws.cost.p;
@@ -2695,6 +2698,9 @@ static int sgm_run_impl(r3d_ctx *ctx, int lane, hipStream_t st, const r3d_sgbm_p
         } else if (g.DP == 64) {
             if (padded) k_hscan2<2, 16, K64, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, 0);
             else k_hscan2<2, 16, K64, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, 0);
+        } else if (four && k8) {
+            if (padded) k_hscan2<4, 16, 8, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, 0);
+            else k_hscan2<4, 16, 8, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, 0);
         } else if (four) {
             if (padded) k_hscan2<4, 16, K1b, true><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, 0);
             else k_hscan2<4, 16, K1b, false><<<nwaves, 64, 0, st>>>(cp, hp, kp, g, 0, 0);
