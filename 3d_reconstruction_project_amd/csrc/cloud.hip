@@ -3246,7 +3246,13 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
     // been consumed -- the device never runs dry while the host notices a batch's end and enqueues the next (that hand-over
     // left the GPU idle for ~40 us per 8 iterations: profiles/r04_icp_timeline.txt).  k_icp_step publishes its state to the
     // host mirror only at the steps the host waits for (every ICP_STRIDE-th and the last).
-    constexpr int ICP_BATCH = 8, ICP_STRIDE = 4;
+    // Large clouds (an evaluation is >= 50 us) get a window of 24, topped up by 8: the default 20- and 30-iteration loops are then
+    // enqueued (almost) whole and do not depend on the host thread being scheduled in time -- the 10-50 ms "device queue not
+    // served" loops of shared boxes were the device running dry behind a descheduled host; evaluations behind the step that ends
+    // the loop return at their first instruction (at most 24 x ~8 us).  R3D_ICP_WINDOW=<batch> overrides (stride = batch / 2).
+    static const int win_env = [] { const char *e = getenv("R3D_ICP_WINDOW"); const int v = e ? atoi(e) : 0; return v < 2 ? 0 : (v > 256 ? 256 : v); }();
+    const bool big = ns >= 500000;
+    const int ICP_BATCH = win_env ? win_env : big ? 24 : 8, ICP_STRIDE = win_env ? std::max(win_env / 2, 1) : big ? 8 : 4;
     bool loop_done = false;
     const int total = max_it + 1;
     for (int enq = 0; enq < total;) {
