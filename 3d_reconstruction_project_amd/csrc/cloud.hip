@@ -51,6 +51,7 @@ struct GridView {
     // the correspondence radius (rs >= ceil(radius / cell)): its search is skipped outright, with the result it would have had.
     const unsigned char *reach;
     int rs, rnx, rny, rnz;
+    int pool;              // registration loop: the packed search pools the lanes' row lists per wave (nn_block_q10's pooled walk)
 };
 
 __device__ __forceinline__ int cell_coord(double v, double o, double inv) { return (int)floor((v - o) * inv); }
@@ -1258,6 +1259,9 @@ __global__ void __launch_bounds__(256) k_soa_f32(const double *__restrict__ pts,
 // to nn_block_global on a fourth contender within the margin) is unchanged, and so is the result: bit-identical to the
 // all-float64 search (tests/test_cloud_gpu.py).  Queries whose nine rows hold more than 1024 candidates use the fallback.
 constexpr float FEQ = 2.25f;
+// pooled walk (nn_block_q10<1>): queue capacity per wave, and words per wave of the pool buffer: keys [Q][4], items [Q][2], the
+// lanes' query parameters [4][64], the queue length
+constexpr int POOL_Q = 256, POOL_W = 6 * POOL_Q + 256 + 4;
 
 __global__ void __launch_bounds__(256) k_pack_q10(GridView g, int64_t n, unsigned *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1296,7 +1300,8 @@ __device__ __forceinline__ void icp_stat(int slot, int v) {
 #endif
 template <int G>
 __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, double py, double pz, int cx, int cy, int cz, double r2,
-                                             double &best, int &bi, int *__restrict__ sRun /* [18][ICP_BLOCK] */) {
+                                             double &best, int &bi, int *__restrict__ sRun /* [18][ICP_BLOCK] */,
+                                             int *__restrict__ sPool = nullptr /* G == 1: [ICP_BLOCK / 64][POOL_W], 16-byte aligned */) {
     constexpr int B = 256;   // = ICP_BLOCK (declared below)
     const int tid = threadIdx.x;
     const int xa = cx - 1, xb = cx + 1;
@@ -1340,31 +1345,38 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
     // four candidates per 16-byte gather; the distance arithmetic runs two candidates per instruction (v_pk_add / v_pk_mul /
     // v_pk_fma_f32: 6 packed instructions per pair instead of 12 scalar ones; lane-wise IEEE, so the keys are unchanged)
     typedef float v2f __attribute__((ext_vector_type(2)));
-    auto scan4w = [&](const uint4_a4 W, int rem, float qyr, float qzr) {
-        int keys[4];
+    // keys of four packed candidates for a query given by (qx_, xsub_, qyr, qzr), ordinals ord_ ..; the lanes of a wave also run this
+    // for EACH OTHER's queries (pooled walk below): same expressions, same operand values, so the same keys whoever computes them
+    auto keys4 = [&](const uint4_a4 W, int rem, float qx_, unsigned xsub_, float qyr, float qzr, int ord_, int (&keys)[4]) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const unsigned w0 = W[2 * h], w1 = W[2 * h + 1];
-            v2f cx2 = {(float)((w0 - xsub) & 4095u), (float)((w1 - xsub) & 4095u)};
-            // y without v_bfe + v_cvt (both ~4.2 cycles per wave on gfx950, tools/micro/valu_rate.hip): the field sits at mantissa bits
-            // 12..21, where a float in [2048, 4096) has weight 1, so (w & mask) | bits(2048.f) IS 2048 + y; two 2.5-cycle instructions,
-            // and the row constant carries the 2048 (rounded to 2^-12 units at most: 1.2e-4 of the 1.1-unit stage-1 error budget)
+            v2f cx2 = {(float)((w0 - xsub_) & 4095u), (float)((w1 - xsub_) & 4095u)};
             v2f cy2 = {__uint_as_float((w0 & 0x003ff000u) | 0x45000000u), __uint_as_float((w1 & 0x003ff000u) | 0x45000000u)};
             v2f cz2 = {(float)(w0 >> 22), (float)(w1 >> 22)};
-            const v2f qx2 = {qx, qx}, qy2 = {qyr + 2048.f, qyr + 2048.f}, qz2 = {qzr, qzr};
+            const v2f qx2 = {qx_, qx_}, qy2 = {qyr + 2048.f, qyr + 2048.f}, qz2 = {qzr, qzr};
             const v2f fdx = cx2 - qx2, fdy = cy2 - qy2, fdz = cz2 - qz2;
             const v2f f = __builtin_elementwise_fma(fdz, fdz, __builtin_elementwise_fma(fdy, fdy, fdx * fdx));
-            keys[2 * h] = (__float_as_int(f.x) & ~1023) | (ord + 2 * h);
-            keys[2 * h + 1] = (__float_as_int(f.y) & ~1023) | (ord + 2 * h + 1);
+            keys[2 * h] = (__float_as_int(f.x) & ~1023) | (ord_ + 2 * h);
+            keys[2 * h + 1] = (__float_as_int(f.y) & ~1023) | (ord_ + 2 * h + 1);
         }
 #pragma unroll
+        for (int u = 0; u < 4; u++) keys[u] = u < rem ? keys[u] : KINF;
+    };
+    auto fold4 = [&](const int (&keys)[4]) {
+#pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int key = u < rem ? keys[u] : KINF;
+            const int key = keys[u];
             k4 = med3_i32(k3, k4, key);
             k3 = med3_i32(k2, k3, key);
             k2 = med3_i32(k1, k2, key);
             k1 = min(k1, key);
         }
+    };
+    auto scan4w = [&](const uint4_a4 W, int rem, float qyr, float qzr) {
+        int keys[4];
+        keys4(W, rem, qx, xsub, qyr, qzr, ord, keys);
+        fold4(keys);
         ord += 4;
     };
     auto scan4 = [&](int j0, int e, float qyr, float qzr) { scan4w(*(const uint4_a4 *)(g.q10 + j0), e - j0, qyr, qzr); };
@@ -1398,7 +1410,7 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
     // the padded lengths, recomputed by the one decode at the end.  Record 0: the centre row (ordinal 0)
     sRun[tid] = rb[0];
     sRun[B + tid] = re[0] - rb[0];
-    int nr = 1;
+    int nr = 1, myg = 0;                            // records, and groups of four candidates in the records after the centre row
 #pragma unroll
     for (int q = 1; q < 9; q++) {
         const int r = ORD[q], ry = r % 3, rz = r / 3;
@@ -1409,6 +1421,7 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
         if (re[q] > rb[q] && e_ > b_ && syz <= thr) {   // (a row outside the grid has re == rb and meaningless cell boundaries)
             sRun[(nr * 2) * B + tid] = b_;
             sRun[(nr * 2 + 1) * B + tid] = (e_ - b_) | (r << 20);
+            myg += (e_ - b_ + 3) >> 2;
             nr++;
         }
     }
@@ -1422,7 +1435,64 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
         icp_stat(14, 1);                            // [14] waves, [15] queries
     }
 #endif
-    {
+    // POOLED WALK of the other rows (G == 1, large clouds).  Left to itself a wave walks its lists for as long as its longest lane:
+    // 9.3 groups on average where its average lane has 2.3 (tools/gpu_icp_stats.py) -- three quarters of the wave's lane-steps
+    // are idle.  Here the lanes put their groups into ONE queue of the wave (LDS), every lane computes the keys of every
+    // (active-lane-count)-th group, whoever's query it belongs to -- the owner's query parameters travel through LDS, the
+    // arithmetic is keys4() with the same operands, so the keys are the ones the owner would have computed -- and the owners
+    // fold their groups' keys into their best four (4 instructions per candidate instead of 20).  A wave whose queue would
+    // overflow takes the per-lane walk below.  R3D_ICP_POOL=0 (host side: no pool buffer is passed) keeps the per-lane walk.
+    bool pooled = false;
+    if (G == 1 && sPool) {
+        int *pw = sPool + (tid >> 6) * POOL_W;
+        int *p_keys = pw, *p_item = pw + 4 * POOL_Q, *p_q = pw + 6 * POOL_Q, *p_tot = pw + 6 * POOL_Q + 256;
+        const int lane = tid & 63;
+        *(volatile int *)p_tot = 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int off = atomicAdd(p_tot, myg);                    // ds_add_rtn: a disjoint range of the queue per lane
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int tot = *(volatile int *)p_tot;                   // the same for every lane of the wave
+        if (tot <= POOL_Q) {
+            pooled = true;
+            p_q[lane] = __float_as_int(qx);
+            p_q[64 + lane] = __float_as_int(qyc);
+            p_q[128 + lane] = __float_as_int(qzc);
+            p_q[192 + lane] = (int)xsub;
+            int it = off, ob = ord;                               // ord: the centre row's padded length
+            for (int k = 1; k < nr; k++) {
+                const int jb = sRun[(k * 2) * B + tid], lr = sRun[(k * 2 + 1) * B + tid], len = lr & 0xfffff, r = lr >> 20;
+                for (int o = 0; o < len; o += 4, it++) {
+                    p_item[2 * it] = jb + o;
+                    p_item[2 * it + 1] = lane | min(len - o, 4) << 6 | r << 9 | (ob + o) << 13;
+                }
+                ob += (len + 3) & ~3;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long act = __ballot(1);
+            const int nact = __popcll(act), rank = __popcll(act & ((1ull << lane) - 1ull));
+            for (int i = rank; i < tot; i += nact) {
+                const int j0 = p_item[2 * i], meta = p_item[2 * i + 1];
+                const int o = meta & 63, rem = (meta >> 6) & 7, r = (meta >> 9) & 15, ordb = (int)((unsigned)meta >> 13);
+                const float oqx = __int_as_float(p_q[o]), oqy = __int_as_float(p_q[64 + o]), oqz = __int_as_float(p_q[128 + o]);
+                const unsigned oxs = (unsigned)p_q[192 + o];
+                const int rz = (r * 11) >> 5, ry = r - 3 * rz;
+                int keys[4];
+                keys4(*(const uint4_a4 *)(g.q10 + j0), rem, oqx, oxs, oqy - 0.5f - 1024.f * (float)ry, oqz - 0.5f - 1024.f * (float)rz, ordb, keys);
+                *(int4 *)(p_keys + 4 * i) = make_int4(keys[0], keys[1], keys[2], keys[3]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int gq = 0; gq < myg; gq++) {
+                const int4 kk = *(const int4 *)(p_keys + 4 * (off + gq));
+                const int keys[4] = {kk.x, kk.y, kk.z, kk.w};
+                fold4(keys);
+            }
+        }
+    }
+    if (!pooled) {
         int k = 1, j0 = 0, e = 0;
         float qyr = 0.f, qzr = 0.f;
         auto next_run = [&]() {     // false: the list is exhausted
@@ -1637,6 +1707,8 @@ __global__ void __launch_bounds__(ICP_BLOCK, SEARCH == SEARCH_Q10_DEEP ? 2 : 3) 
                                                         int *__restrict__ corr /* optional [ns] target original index or -1 */) {
     static_assert(ICP_BLOCK == 256, "nn_block_q10 assumes 256 threads");
     __shared__ int sRun[SEARCH >= SEARCH_Q10 ? 18 * ICP_BLOCK : 1];
+    __shared__ __attribute__((aligned(16))) int sPoolBuf[SEARCH == SEARCH_Q10 ? (ICP_BLOCK / 64) * POOL_W : 4];
+    int *const sPool = SEARCH == SEARCH_Q10 && g.pool ? sPoolBuf : nullptr;
     if (st->done) return;                        // the loop ended in an earlier launch of this batch (uniform)
     const Rigid T = load_rigid(st);
     double acc[ICP_SLOTS];
@@ -1667,7 +1739,7 @@ __global__ void __launch_bounds__(ICP_BLOCK, SEARCH == SEARCH_Q10_DEEP ? 2 : 3) 
         int bi = -1;
         if (!icp_out_of_reach(g, cx, cy, cz)) {
             if (SEARCH == SEARCH_Q10_DEEP) nn_block_q10<3>(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun);
-            else if (SEARCH == SEARCH_Q10) nn_block_q10<1>(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun);
+            else if (SEARCH == SEARCH_Q10) nn_block_q10<1>(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun, sPool);
             else if (SEARCH == SEARCH_F32) nn_block_top4(g, px, py, pz, cx, cy, cz, best, bi);
             else nn_block_global(g, px, py, pz, cx, cy, cz, best, bi);
             nn_outer_shells(g, px, py, pz, cx, cy, cz, smax, best, bi);
@@ -1699,6 +1771,8 @@ template <int SEARCH>
 __global__ void __launch_bounds__(ICP_BLOCK, 4) k_icp_search(GridView g, const double *__restrict__ src, int64_t ns, const IcpState *__restrict__ st,
                                                              double max_dist, int *__restrict__ nn) {
     __shared__ int sRun[SEARCH >= SEARCH_Q10 ? 18 * ICP_BLOCK : 1];
+    __shared__ __attribute__((aligned(16))) int sPoolBuf[SEARCH == SEARCH_Q10 ? (ICP_BLOCK / 64) * POOL_W : 4];
+    int *const sPool = SEARCH == SEARCH_Q10 && g.pool ? sPoolBuf : nullptr;
     if (st->done) return;
     const Rigid T = load_rigid(st);
     const double r2 = max_dist * max_dist;
@@ -1723,7 +1797,7 @@ __global__ void __launch_bounds__(ICP_BLOCK, 4) k_icp_search(GridView g, const d
         int bi = -1;
         if (!icp_out_of_reach(g, cx, cy, cz)) {
             if (SEARCH == SEARCH_Q10_DEEP) nn_block_q10<3>(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun);
-            else if (SEARCH == SEARCH_Q10) nn_block_q10<1>(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun);
+            else if (SEARCH == SEARCH_Q10) nn_block_q10<1>(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun, sPool);
             else if (SEARCH == SEARCH_F32) nn_block_top4(g, px, py, pz, cx, cy, cz, best, bi);
             else nn_block_global(g, px, py, pz, cx, cy, cz, best, bi);
             nn_outer_shells(g, px, py, pz, cx, cy, cz, smax, best, bi);
@@ -3096,6 +3170,9 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
             unsigned *q = (unsigned *)ar.get((size_t)(nt + 4) * sizeof(unsigned));
             if (ar.rc) return ar.rc;
             G.v.q10 = q;
+            // R3D_ICP_POOL=0: every lane walks its own row lists (rounds 2-3; A/B)
+            static const bool pool_env = [] { const char *e = getenv("R3D_ICP_POOL"); return !(e && !strcmp(e, "0")); }();
+            G.v.pool = pool_env ? 1 : 0;
             k_pack_q10<<<(unsigned)((nt + 4 + 255) / 256), 256, 0, ctx->stream>>>(G.v, nt, q);
             R3D_HIP(ctx, hipGetLastError());
         } else if (!want_exact && 4.0 * e < 0.25 * G.v.cell && M < 1e30) {
