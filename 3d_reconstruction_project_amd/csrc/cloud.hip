@@ -1771,8 +1771,7 @@ template <int SEARCH>
 __global__ void __launch_bounds__(ICP_BLOCK, 4) k_icp_search(GridView g, const double *__restrict__ src, int64_t ns, const IcpState *__restrict__ st,
                                                              double max_dist, int *__restrict__ nn) {
     __shared__ int sRun[SEARCH >= SEARCH_Q10 ? 18 * ICP_BLOCK : 1];
-    __shared__ __attribute__((aligned(16))) int sPoolBuf[SEARCH == SEARCH_Q10 ? (ICP_BLOCK / 64) * POOL_W : 4];
-    int *const sPool = SEARCH == SEARCH_Q10 && g.pool ? sPoolBuf : nullptr;
+    int *const sPool = nullptr;   // (the pooled walk's 28 KB of LDS would cost this kernel its fourth workgroup per CU, the point of the split)
     if (st->done) return;
     const Rigid T = load_rigid(st);
     const double r2 = max_dist * max_dist;
@@ -2857,6 +2856,17 @@ __global__ void __launch_bounds__(1024) k_icp_step(const double *__restrict__ pa
     __shared__ double sums[32];
     if (st->done) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // the state the one deciding thread needs, requested BEFORE the reduction so that its round trips run under the partial sums'
+    // (they were a chain of dependent loads after the barrier)
+    int k = 0;
+    double fit0 = 0, rmse0 = 0, T[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) T[i] = 0;
+    if (threadIdx.x == 0) {
+        k = st->evals; fit0 = st->fit; rmse0 = st->rmse;
+#pragma unroll
+        for (int i = 0; i < 16; i++) T[i] = st->T[i];
+    }
     {
         // wave w owns slots w and w + 16; the partial sums are stored [slot][workgroup], so lane t reads t, t + 64, ... of a
         // contiguous run, twelve requests per slot in flight (768 workgroups = one round), added in ascending order: the same
@@ -2885,13 +2895,12 @@ __global__ void __launch_bounds__(1024) k_icp_step(const double *__restrict__ pa
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    const int k = st->evals;
     const unsigned long long now = wall_clock64();
     if (k == 0) st->t_first = now;
     st->t_last = now;
     const double fit = sums[0] / (double)ns, rmse = sums[0] > 0 ? sqrt(sums[1] / sums[0]) : 0.0;
     int stop = 0;
-    if (k >= 1 && fabs(st->fit - fit) < rel_fit && fabs(st->rmse - rmse) < rel_rmse) { st->converged = 1; st->iterations = k; stop = 1; }
+    if (k >= 1 && fabs(fit0 - fit) < rel_fit && fabs(rmse0 - rmse) < rel_rmse) { st->converged = 1; st->iterations = k; stop = 1; }
     else if (k >= max_it) { st->iterations = max_it; stop = 1; }
     st->fit = fit; st->rmse = rmse; st->corr = sums[0];
     st->evals = k + 1;
@@ -2902,8 +2911,6 @@ __global__ void __launch_bounds__(1024) k_icp_step(const double *__restrict__ pa
         if (mode == MODE_P2P) umeyama_from_sums(sums, U);
         else solve6_to_matrix(sums, U);
     }
-    double T[16];
-    for (int i = 0; i < 16; i++) T[i] = st->T[i];
     mat4_mul(U, T, T);
     for (int i = 0; i < 16; i++) st->T[i] = T[i];
     if (publish) icp_publish(st, mirror);   // (a publish is ~20 posted writes to host memory and a system-scope fence: not once per step)
