@@ -1261,7 +1261,8 @@ __global__ void __launch_bounds__(256) k_soa_f32(const double *__restrict__ pts,
 constexpr float FEQ = 2.25f;
 // pooled walk (nn_block_q10<1>): queue capacity per wave, and words per wave of the pool buffer: keys [Q][4], items [Q][2], the
 // lanes' query parameters [4][64], the queue length
-constexpr int POOL_Q = 256, POOL_W = 6 * POOL_Q + 256 + 4;
+constexpr int POOL_Q = 256, POOL_Q_SEARCH = 176 /* k_icp_search: four workgroups' LDS still fit a CU */;
+constexpr int pool_words(int q) { return 6 * q + 256 + 4; }
 
 __global__ void __launch_bounds__(256) k_pack_q10(GridView g, int64_t n, unsigned *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1298,10 +1299,10 @@ __device__ __forceinline__ void icp_stat(int slot, int v) {
     if ((threadIdx.x & 63) == 0) { atomicAdd(&g_icp_stats[slot], (unsigned long long)m); atomicAdd(&g_icp_stats[slot + 1], (unsigned long long)sum); }
 }
 #endif
-template <int G>
+template <int G, int PQ = POOL_Q>
 __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, double py, double pz, int cx, int cy, int cz, double r2,
                                              double &best, int &bi, int *__restrict__ sRun /* [18][ICP_BLOCK] */,
-                                             int *__restrict__ sPool = nullptr /* G == 1: [ICP_BLOCK / 64][POOL_W], 16-byte aligned */) {
+                                             int *__restrict__ sPool = nullptr /* G == 1: [ICP_BLOCK / 64][pool_words(PQ)], 16-byte aligned */) {
     constexpr int B = 256;   // = ICP_BLOCK (declared below)
     const int tid = threadIdx.x;
     const int xa = cx - 1, xb = cx + 1;
@@ -1444,8 +1445,8 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
     // overflow takes the per-lane walk below.  R3D_ICP_POOL=0 (host side: no pool buffer is passed) keeps the per-lane walk.
     bool pooled = false;
     if (G == 1 && sPool) {
-        int *pw = sPool + (tid >> 6) * POOL_W;
-        int *p_keys = pw, *p_item = pw + 4 * POOL_Q, *p_q = pw + 6 * POOL_Q, *p_tot = pw + 6 * POOL_Q + 256;
+        int *pw = sPool + (tid >> 6) * pool_words(PQ);
+        int *p_keys = pw, *p_item = pw + 4 * PQ, *p_q = pw + 6 * PQ, *p_tot = pw + 6 * PQ + 256;
         const int lane = tid & 63;
         *(volatile int *)p_tot = 0;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1454,7 +1455,7 @@ __device__ __forceinline__ void nn_block_q10(const GridView &g, double px, doubl
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int tot = *(volatile int *)p_tot;                   // the same for every lane of the wave
-        if (tot <= POOL_Q) {
+        if (tot <= PQ) {
             pooled = true;
             p_q[lane] = __float_as_int(qx);
             p_q[64 + lane] = __float_as_int(qyc);
@@ -1707,7 +1708,7 @@ __global__ void __launch_bounds__(ICP_BLOCK, SEARCH == SEARCH_Q10_DEEP ? 2 : 3) 
                                                         int *__restrict__ corr /* optional [ns] target original index or -1 */) {
     static_assert(ICP_BLOCK == 256, "nn_block_q10 assumes 256 threads");
     __shared__ int sRun[SEARCH >= SEARCH_Q10 ? 18 * ICP_BLOCK : 1];
-    __shared__ __attribute__((aligned(16))) int sPoolBuf[SEARCH == SEARCH_Q10 ? (ICP_BLOCK / 64) * POOL_W : 4];
+    __shared__ __attribute__((aligned(16))) int sPoolBuf[SEARCH == SEARCH_Q10 ? (ICP_BLOCK / 64) * pool_words(POOL_Q) : 4];
     int *const sPool = SEARCH == SEARCH_Q10 && g.pool ? sPoolBuf : nullptr;
     if (st->done) return;                        // the loop ended in an earlier launch of this batch (uniform)
     const Rigid T = load_rigid(st);
@@ -1771,7 +1772,9 @@ template <int SEARCH>
 __global__ void __launch_bounds__(ICP_BLOCK, 4) k_icp_search(GridView g, const double *__restrict__ src, int64_t ns, const IcpState *__restrict__ st,
                                                              double max_dist, int *__restrict__ nn) {
     __shared__ int sRun[SEARCH >= SEARCH_Q10 ? 18 * ICP_BLOCK : 1];
-    int *const sPool = nullptr;   // (the pooled walk's 28 KB of LDS would cost this kernel its fourth workgroup per CU, the point of the split)
+    // a smaller queue than k_icp_eval's (176 groups per wave: 21 KB): with the 18 KB of row lists four workgroups still fit a CU
+    __shared__ __attribute__((aligned(16))) int sPoolBuf[SEARCH == SEARCH_Q10 ? (ICP_BLOCK / 64) * pool_words(POOL_Q_SEARCH) : 4];
+    int *const sPool = SEARCH == SEARCH_Q10 && g.pool ? sPoolBuf : nullptr;
     if (st->done) return;
     const Rigid T = load_rigid(st);
     const double r2 = max_dist * max_dist;
@@ -1796,7 +1799,7 @@ __global__ void __launch_bounds__(ICP_BLOCK, 4) k_icp_search(GridView g, const d
         int bi = -1;
         if (!icp_out_of_reach(g, cx, cy, cz)) {
             if (SEARCH == SEARCH_Q10_DEEP) nn_block_q10<3>(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun);
-            else if (SEARCH == SEARCH_Q10) nn_block_q10<1>(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun, sPool);
+            else if (SEARCH == SEARCH_Q10) nn_block_q10<1, POOL_Q_SEARCH>(g, px, py, pz, cx, cy, cz, r2, best, bi, sRun, sPool);
             else if (SEARCH == SEARCH_F32) nn_block_top4(g, px, py, pz, cx, cy, cz, best, bi);
             else nn_block_global(g, px, py, pz, cx, cy, cz, best, bi);
             nn_outer_shells(g, px, py, pz, cx, cy, cz, smax, best, bi);
