@@ -3343,8 +3343,14 @@ static int icp_core(r3d_ctx *ctx, DevArena &ar, const r3d_icp_params *p, double 
     bool loop_done = false;
     const int total = max_it + 1;
     for (int enq = 0; enq < total;) {
-        for (int b = 0, nb = enq == 0 ? ICP_BATCH : ICP_STRIDE; b < nb && enq < total; b++, enq++)
-            enqueue_eval(wait_event || (enq + 1) % ICP_STRIDE == 0 || enq + 1 == total);
+        for (int b = 0, nb = enq == 0 ? ICP_BATCH : ICP_STRIDE; b < nb && enq < total; b++, enq++) {
+            // a step publishes its state to the host mirror (~20 posted writes and a system-scope fence) only if the host will WAIT
+            // for it: the last one, and the steps `need` below names (ICP_BATCH - ICP_STRIDE, then every ICP_STRIDE-th, while more
+            // evaluations remain to be enqueued behind them); a step that ENDS the loop publishes by itself
+            const int sno = enq + 1, first_need = ICP_BATCH - ICP_STRIDE;
+            const bool awaited = sno == total || (sno >= first_need && (sno - first_need) % ICP_STRIDE == 0 && sno + ICP_STRIDE < total);
+            enqueue_eval(wait_event || awaited);
+        }
         R3D_HIP(ctx, hipGetLastError());
         if (wait_event) {
             R3D_HIP(ctx, hipMemcpyAsync(hst, d_st, sizeof *hst, hipMemcpyDeviceToHost, ctx->stream));
