@@ -1902,18 +1902,39 @@ __global__ void __launch_bounds__(256) k_lrcheck(const int16_t *__restrict__ raw
     const int16_t *r = raw + (size_t)y * W, *m = mins + (size_t)y * W;
     for (int x = threadIdx.x; x < W; x += 256) keys[x] = 0xffffffffu;
     __syncthreads();
-    for (int x = g.minX1 + threadIdx.x; x < g.maxX1; x += 256) {
-        const int d1 = r[x];
-        if (d1 == g.invalid) continue;
-        const int d = (d1 + 7) >> 4;  // best + minD (sub-pixel offset lies in [-7, 8])
-        const int x2 = x - d;
-        atomicMin(&keys[x2], ((unsigned)((int)m[x] + 32768) << 16) | (unsigned)(W - 1 - x));
+    // four strides of loads in flight per thread (a rolled loop waits for each 2-byte load before the next: 13 dependent round
+    // trips per phase at C2's width were most of this kernel's 41 us)
+    for (int x0 = g.minX1 + (int)threadIdx.x; x0 < g.maxX1; x0 += 4 * 256) {
+        int d1v[4], mv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int x = min(x0 + 256 * u, g.maxX1 - 1);
+            d1v[u] = r[x]; mv[u] = m[x];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int x = x0 + 256 * u, d1 = d1v[u];
+            if (x >= g.maxX1 || d1 == g.invalid) continue;
+            const int d = (d1 + 7) >> 4;  // best + minD (sub-pixel offset lies in [-7, 8])
+            const int x2 = x - d;
+            atomicMin(&keys[x2], ((unsigned)(mv[u] + 32768) << 16) | (unsigned)(W - 1 - x));
+        }
     }
     __syncthreads();
-    for (int x = threadIdx.x; x < W; x += 256) {
+    int d1n[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) d1n[u] = r[min((int)threadIdx.x + 256 * u, W - 1)];
+    for (int xb = (int)threadIdx.x; xb < W; xb += 4 * 256) {
+        int d1c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { d1c[u] = d1n[u]; d1n[u] = r[min(xb + 4 * 256 + 256 * u, W - 1)]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+        const int x = xb + 256 * u;
+        if (x >= W) continue;
         int d1 = g.invalid;
         if (x >= g.minX1 && x < g.maxX1) {
-            d1 = r[x];
+            d1 = d1c[u];
             if (d1 != g.invalid) {
                 const int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
                 const int _x = x - _d, x_ = x - d_;
@@ -1932,6 +1953,7 @@ __global__ void __launch_bounds__(256) k_lrcheck(const int16_t *__restrict__ raw
             }
         }
         out[(size_t)y * W + x] = (int16_t)d1;
+        }
     }
 }
 
