@@ -317,10 +317,12 @@ __global__ void __launch_bounds__(256) k_prefilter(const uint8_t *__restrict__ L
     const int xc = min(max(x0 - 2 + t, 0), W - 1), xe = min(max(x0 + 254 + (t & 3), 0), W - 1);
     auto px = [&](int yy, int xx) { return (int)img[(size_t)min(max(yy, 0), H - 1) * ld + xx]; };
     int a = px(yb - 1, xc), r = px(yb, xc), ae = px(yb - 1, xe), re = px(yb, xe);
+    int bn = px(yb + 1, xc), ben = px(yb + 1, xe);   // the row below, requested ONE iteration early (its round trip ran on the critical path of every row)
     const int x = x0 + t;
     const bool hm = x > 0, hp = x < W - 1;
     for (int y = yb; y < min(yb + PF_ROWS, H); y++) {
-        const int b = px(y + 1, xc), be = px(y + 1, xe);
+        const int b = bn, be = ben;
+        bn = px(y + 2, xc); ben = px(y + 2, xe);
         raw[t] = a | (r << 8) | (b << 16);
         if (t < 4) raw[256 + t] = ae | (re << 8) | (be << 16);
         a = r; r = b; ae = re; re = be;
